@@ -1,0 +1,176 @@
+/*
+ * posegen_hip.h -- C ABI of the MI355X-native A-NeRF renderer (libposegen_hip.so).
+ *
+ * The reference (mgholamikn/PoseGen) has no FFI: its renderer is the Python object
+ * stored under render_kwargs['ray_caster'] (core/raycasters.py:156-178), called at
+ * exactly one site, core/trainer.py:74.  This header is the boundary that object's
+ * MI355X replacement (posegen_amd.HipRayCaster) binds through ctypes; every entry
+ * point names the reference code it replaces.  SURVEY.md section 8(b).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PG_E* code and never throws;
+ *     pg_last_error() returns a human-readable message for the last failure
+ *   - pointers are borrowed for the duration of the call
+ *   - `stream` is a hipStream_t (torch's current HIP stream); pg_render_rays and the
+ *     pg_stage_* entry points are asynchronous with respect to the host
+ *   - "device pointer" = memory of the handle's HIP device
+ *   - calls on one handle must be serialised by the caller (not re-entrant)
+ */
+#ifndef POSEGEN_HIP_H
+#define POSEGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+/* error codes */
+#define PG_OK 0
+#define PG_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define PG_ENOMEM (-2)      /* device allocation failed */
+#define PG_EHIP (-3)        /* a HIP runtime call failed */
+#define PG_ESTATE (-4)      /* weights / embedder not loaded yet */
+
+/* precision of the fused embed+MLP kernel (arithmetic of the MFMA operands;
+ * accumulation, biases, embedding and compositing are always fp32) */
+#define PG_PREC_FP32 0      /* v_mfma_f32_32x32x2_f32, exact fp32 chain (parity mode) */
+#define PG_PREC_BF16 1      /* bf16 x bf16 (BASELINE config 2) */
+#define PG_PREC_BF16X3 2    /* split bf16: hi*hi + hi*lo + lo*hi */
+#define PG_PREC_FP16 3      /* fp16 x fp16 */
+#define PG_PREC_FP16X3 4    /* split fp16: hi*hi + hi*lo + lo*hi */
+#define PG_PREC_COUNT 5
+
+/* flags of pg_render_rays */
+#define PG_FLAG_LINDISP 1   /* sample linearly in inverse depth (ray_utils.py:224-227) */
+
+/* Network / embedding description: the subset of the reference's flags that shapes
+ * the renderer (run_nerf.py:186-490; create_raycaster, core/raycasters.py:17-184).
+ * The kernels are specialised for the architecture every shipped reference config
+ * uses: 24 joints, multires 7/4/0, 8x256 trunk with the skip after layer 4,
+ * 128-wide view layer; pg_create rejects anything else with PG_EINVAL. */
+typedef struct pg_config {
+    int32_t n_joints;        /* 24                       SMPLSkeleton                 */
+    int32_t multires;        /* 7                        --multires                   */
+    int32_t multires_views;  /* 4                        --multires_views             */
+    int32_t multires_bones;  /* 0                        --multires_bones             */
+    int32_t net_depth;       /* 8                        --netdepth                   */
+    int32_t net_width;       /* 256                      --netwidth                   */
+    int32_t skip_layer;      /* 4                        raycasters.py:82             */
+    int32_t view_width;      /* 128 = net_width/2        nerf.py:78                   */
+    int32_t framecode_ch;    /* 0, or 16 with --opt_framecode (nerf.py:86-87)         */
+    int32_t n_framecodes;    /* rows of framecodes.codes.weight                       */
+    int32_t chunk;           /* rays per nanmean group = --chunk (trainer.py:64-81)   */
+    int32_t precision;       /* PG_PREC_*                                             */
+    float cutoff_dist;       /* cutoff_mm * ext_scale   (raycasters.py:33)            */
+    float density_scale;     /* --density_scale (B of raw2outputs)                    */
+    float rgb_eps;           /* 1e-3                     nerf.py:151                  */
+    float reserved0;
+} pg_config;
+
+/* Device output pointers of one pg_render_rays call; any may be NULL (not wanted).
+ * Keys of RayCaster._collect_outputs (core/raycasters.py:711-724). */
+typedef struct pg_outputs {
+    float* rgb_map;   /* [n,3]                      fine (or coarse if N_importance==0) */
+    float* disp_map;  /* [n]                                                          */
+    float* acc_map;   /* [n]                                                          */
+    float* alpha;     /* [n, N_samples+N_importance]                                  */
+    float* rgb0;      /* [n,3]   coarse pass (only written when N_importance > 0)     */
+    float* disp0;     /* [n]                                                          */
+    float* acc0;      /* [n]                                                          */
+    float* alpha0;    /* [n, N_samples]                                               */
+    /* optional intermediates (tests / debugging), reference names in comments */
+    float* near_far;  /* [n,2]  get_near_far_in_cylinder                              */
+    float* z_coarse;  /* [n, N_samples]                 sample_from_lineseg           */
+    float* z_fine;    /* [n, N_samples+N_importance]    isample_from_lineseg (sorted) */
+    float* raw_coarse;/* [n, N_samples, 4]              run_network(network)          */
+    float* raw_fine;  /* [n, N_samples+N_importance, 4] run_network(network_fine)     */
+    float* weights0;  /* [n, N_samples]                 raw2outputs 'weights'         */
+} pg_outputs;
+
+typedef struct pg_handle pg_handle;
+
+int pg_abi_version(void);
+
+/* Replaces create_raycaster (core/raycasters.py:17-184): builds the renderer for one
+ * HIP device.  n_devices must be 1 (one process per GPU; frames are partitioned
+ * across ranks by the host). */
+int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_handle** out);
+void pg_destroy(pg_handle* h);
+const char* pg_last_error(const pg_handle* h);   /* h may be NULL: last global error */
+
+/* Replaces RayCaster.load_state_dict / load_ckpt_from_path (core/raycasters.py:768-788,
+ * core/cutoff_embedder.py:227-238).  which_net: 0 = 'network_fn_state_dict' (coarse),
+ * 1 = 'network_fine_state_dict'.  tensors[i] are HOST fp32 arrays in nn.Linear layout
+ * [out,in] row-major, in this fixed order (n_tensors = 24):
+ *   pts_linears.{0..7}.weight, pts_linears.{0..7}.bias,        (index 2*l, 2*l+1)
+ *   alpha_linear.{weight,bias}, feature_linear.{weight,bias},
+ *   views_linears.0.{weight,bias}, rgb_linear.{weight,bias}
+ * shapes: 2 int64 per tensor (rows, cols; cols = 1 for biases); checked. */
+int pg_load_weights(pg_handle* h, int which_net, const float* const* tensors,
+                    const int64_t* shapes, int n_tensors);
+
+/* CutoffEmbedder state: which 0 = embed_fn ('embed_state_dict'), 1 = embeddirs_fn
+ * ('embeddirs_state_dict'): cutoff_dist Parameter[24] and the tau buffer
+ * (core/cutoff_embedder.py:89-94, 181-183). */
+int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau);
+
+/* framecodes.codes.weight [n_codes, framecode_ch] (core/networks/embedding.py:6-46);
+ * a row holding the mean code is appended internally (eval with idx < 0). */
+int pg_set_framecodes(pg_handle* h, int which_net, const float* codes, int n_codes);
+
+/* Select the MFMA operand precision (PG_PREC_*) for subsequent renders. */
+int pg_set_precision(pg_handle* h, int precision);
+
+/* Rays per nanmean group for subsequent renders: the `chunk` argument of render_path /
+ * batchify_rays (run_nerf.py:28, core/trainer.py:64); callers pass different values
+ * (run_gan.py:2318 args.chunk, run_nerf.py:157 args.chunk//8). */
+int pg_set_chunk(pg_handle* h, int chunk);
+
+/* Replaces RayCaster.forward / render_rays in eval mode (core/raycasters.py:345-474):
+ * near/far in cylinder (per `chunk`-ray group nanmean patch), coarse samples, bone
+ * relative embedding, coarse MLP, compositing, deterministic importance samples,
+ * fine MLP on the merged samples, compositing.
+ *   ray_batch [n,11] device: (o, d, near, far, viewdir) as packed by trainer.py:118-137
+ *   skts      [*,24,4,4] device, row-major; pose_stride = floats between consecutive
+ *             rays' pose (0 = one pose shared by all n rays, 384 = per-ray poses)
+ *   cyls      [*,5] device (cx, cz, radius, top, bot); cyl_stride likewise (0 or 5)
+ *   cams      [n] device float frame-code indices or NULL (NULL / negative -> mean code)
+ * kps and bones of the reference call are numerically dead for the shipped encoders
+ *  and are not part of the ABI. */
+int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch,
+                   const float* skts, int64_t pose_stride,
+                   const float* cyls, int64_t cyl_stride, const float* cams,
+                   int n_samples, int n_importance, int flags, const pg_outputs* out);
+
+/* ---- stage entry points (same kernels, exposed for parity tests and profiling) ---- */
+
+/* get_near_far_in_cylinder + sample_from_lineseg (ray_utils.py:204-251, 292-344). */
+int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* ray_batch,
+                           const float* cyls, int64_t cyl_stride, int n_samples, int flags,
+                           float* near_far /*[n,2]*/, float* z /*[n,S]*/);
+
+/* encode_inputs + run_network (raycasters.py:476-577, nerf.py:90-148) on n*S points
+ * p = o + d*z: the fused embedding + MLP kernel.  raw [n,S,4] = (rgb_raw, sigma_raw).
+ * dbg (optional) receives the fp32 pre-activation of density layer 0 [n*S,256]. */
+int pg_stage_eval(pg_handle* h, void* stream, int which_net, int64_t n, int n_samples,
+                  const float* ray_batch, const float* z, const float* skts,
+                  int64_t pose_stride, const float* cams, float* raw, float* dbg);
+
+/* raw2outputs (nerf.py:150-205) and, if n_importance > 0, isample_from_lineseg
+ * (ray_utils.py:157-201, 255-289): wave-per-ray prefix-product compositing. */
+int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
+                       const float* ray_batch, const float* z, const float* raw,
+                       float* rgb, float* disp, float* acc, float* alpha, float* weights,
+                       int n_importance, float* z_fine /*[n,S+N] or NULL*/);
+
+/* Static facts for the host: bytes of the packed weight stream of one net, and the
+ * MFMA instructions one 32-point group issues, for the given precision. */
+int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEGEN_HIP_H */

@@ -87,6 +87,11 @@ class OracleConfig:
     tau_d: float = 20.0          # CutoffEmbedder.tau of embeddirs_fn
     density_scale: float = 1.0
     rgb_eps: float = 1e-3
+    # None = the reference's fp32.  'bf16' / 'fp16' / 'bf16x3' / 'fp16x3' EMULATE the MFMA
+    # operand rounding of the HIP kernel's precision modes (operands rounded to the 16-bit
+    # type, or split into hi+lo halves with the lo*lo term dropped; products exact, fp32
+    # accumulate) so that layout bugs can be told from rounding.
+    quant: Optional[str] = None
 
     @property
     def ch_v(self) -> int:
@@ -357,17 +362,33 @@ def embed_points(pts, rays_d, skts, cfg: OracleConfig, cams=None):
 # ----------------------------------------------------------------------------
 # a-12: NeRF MLP
 # ----------------------------------------------------------------------------
+def _round16(t, q):
+    dt = torch.bfloat16 if q.startswith("bf16") else torch.float16
+    return t.to(dt).to(torch.float32)
+
+
+def _linear(x, w, b, quant: Optional[str]):
+    """F.linear with the operand rounding of the kernel's precision modes (see OracleConfig)."""
+    if quant is None:
+        return F.linear(x, w, b)
+    xh, wh = _round16(x, quant), _round16(w, quant)
+    if not quant.endswith("x3"):
+        return F.linear(xh, wh, b)
+    xl, wl = _round16(x - xh, quant), _round16(w - wh, quant)
+    return F.linear(xh, wh, b) + F.linear(xh, wl) + F.linear(xl, wh)
+
+
 def mlp_forward(x, weights: Dict[str, torch.Tensor], cfg: OracleConfig):
     """x [P, 1080(+1)] -> raw [P,4] = (rgb_raw, sigma_raw) (nerf.py:94-148)."""
     din, dv = cfg.ch_density_in, cfg.ch_d
     x_in, x_view = x[:, :din], x[:, din:din + dv]
     h = x_in
     for i in range(cfg.net_depth):
-        h = F.relu(F.linear(h, weights[f"pts_linears.{i}.weight"], weights[f"pts_linears.{i}.bias"]))
+        h = F.relu(_linear(h, weights[f"pts_linears.{i}.weight"], weights[f"pts_linears.{i}.bias"], cfg.quant))
         if i in cfg.skips:
             h = torch.cat([x_in, h], -1)
-    sigma = F.linear(h, weights["alpha_linear.weight"], weights["alpha_linear.bias"])
-    feat = F.linear(h, weights["feature_linear.weight"], weights["feature_linear.bias"])
+    sigma = _linear(h, weights["alpha_linear.weight"], weights["alpha_linear.bias"], cfg.quant)
+    feat = _linear(h, weights["feature_linear.weight"], weights["feature_linear.bias"], cfg.quant)
     if cfg.framecode_ch > 0:
         idx = x[:, din + dv]
         codes = weights["framecodes.codes.weight"]
@@ -376,9 +397,9 @@ def mlp_forward(x, weights: Dict[str, torch.Tensor], cfg: OracleConfig):
         else:
             code = codes[idx.long()]
         x_view = torch.cat([x_view, code], -1)
-    g = F.relu(F.linear(torch.cat([feat, x_view], -1),
-                        weights["views_linears.0.weight"], weights["views_linears.0.bias"]))
-    rgb = F.linear(g, weights["rgb_linear.weight"], weights["rgb_linear.bias"])
+    g = F.relu(_linear(torch.cat([feat, x_view], -1),
+                       weights["views_linears.0.weight"], weights["views_linears.0.bias"], cfg.quant))
+    rgb = _linear(g, weights["rgb_linear.weight"], weights["rgb_linear.bias"], cfg.quant)
     return torch.cat([rgb, sigma], -1)
 
 

@@ -15,10 +15,10 @@ PREC_FP32 = 0     # f32-input MFMA, exact fp32 chain (parity mode)
 PREC_BF16 = 1     # bf16 operands, fp32 accumulate (throughput mode, BASELINE config 2)
 PREC_BF16X3 = 2   # split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate
 PREC_FP16 = 3     # fp16 operands, fp32 accumulate
-PREC_FP16X2 = 4   # fp16 activations x (hi+lo) fp16 weights, fp32 accumulate
+PREC_FP16X3 = 4   # split-fp16: hi*hi + hi*lo + lo*hi, fp32 accumulate
 
 PREC_NAMES = {PREC_FP32: "fp32", PREC_BF16: "bf16", PREC_BF16X3: "bf16x3",
-              PREC_FP16: "fp16", PREC_FP16X2: "fp16x2"}
+              PREC_FP16: "fp16", PREC_FP16X3: "fp16x3"}
 PREC_BY_NAME = {v: k for k, v in PREC_NAMES.items()}
 
 

@@ -1,0 +1,418 @@
+// pg_api.hip -- C ABI of libposegen_hip.so (include/posegen_hip.h): handle, weight
+// packing / upload, workspace, and the launch sequence of one render_rays call.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/posegen_hip.h"
+#include "pg_device.h"
+#include "pg_pack.h"
+
+extern "C" {
+int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_eval16_points_per_pass(void);
+int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
+int pg_eval32_points_per_pass(void);
+int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
+                            int S, int lindisp, float* near_far, float* z, void* stream);
+int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
+                        float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
+                        float* weights, int n_imp, float* z_fine, void* stream);
+int pg_composite_max_samples(void);
+int pg_composite_max_importance(void);
+}
+
+namespace {
+
+using namespace pgl;
+
+char g_last_error[512] = "";
+
+struct NetState {
+    bool loaded = false;
+    std::vector<std::vector<float>> host;      // 24 tensors, reference order (see header)
+    std::vector<float> codes_host;             // [n_codes+1,16]
+    int n_codes = 0;
+    uint8_t* d_stream[PG_PREC_COUNT] = {};
+    size_t stream_bytes[PG_PREC_COUNT] = {};
+    float* d_bias = nullptr;
+    float* d_codes = nullptr;
+};
+
+}  // namespace
+
+struct pg_handle {
+    pg_config cfg;
+    int device = 0;
+    int n_cu = 256;
+    char err[512] = "";
+    NetState net[2];
+    float cut[48];
+    float tau[2] = {20.f, 20.f};
+    bool emb_set[2] = {false, false};
+    float* d_cut = nullptr;
+    uint8_t* ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+int fail(pg_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    std::snprintf(g_last_error, sizeof g_last_error, "%s", buf);
+    if (h) std::snprintf(h->err, sizeof h->err, "%s", buf);
+    return code;
+}
+
+#define PG_HIP(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, PG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+bool is_shape_a(int prec) { return prec == PG_PREC_BF16 || prec == PG_PREC_FP16; }
+
+pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
+    pgpack::NetTensors t;
+    for (int l = 0; l < DEPTH; ++l) {
+        t.lw[l] = ns.host[2 * l].data();
+        t.lb[l] = ns.host[2 * l + 1].data();
+        t.lcols[l] = l == 0 ? CH_X : (l == SKIP + 1 ? CH_X + W : W);
+    }
+    t.alpha_w = ns.host[16].data(); t.alpha_b = ns.host[17].data();
+    t.feat_w = ns.host[18].data();  t.feat_b = ns.host[19].data();
+    t.view_w = ns.host[20].data();  t.view_b = ns.host[21].data();
+    t.view_cols = W + CH_D + cfg.framecode_ch;
+    t.rgb_w = ns.host[22].data();   t.rgb_b = ns.host[23].data();
+    return t;
+}
+
+int ensure_stream(pg_handle* h, int which, int prec) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (ns.d_stream[prec]) return PG_OK;
+    std::vector<uint8_t> packed;
+    const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, packed);
+    if (rc != 0) return fail(h, PG_EINVAL, "weight stream packing failed (%d) for precision %d", rc, prec);
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec]), packed.size()));
+    PG_HIP(h, hipMemcpy(ns.d_stream[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
+    ns.stream_bytes[prec] = packed.size();
+    return PG_OK;
+}
+
+int ensure_ws(pg_handle* h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return PG_OK;
+    PG_HIP(h, hipSetDevice(h->device));
+    if (h->ws) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    const size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->ws), want);
+    if (e != hipSuccess) return fail(h, PG_ENOMEM, "workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    h->ws_bytes = want;
+    return PG_OK;
+}
+
+int check_ready(pg_handle* h, bool need_fine) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (!h->net[0].loaded) return fail(h, PG_ESTATE, "coarse network weights not loaded (pg_load_weights)");
+    if (need_fine && !h->net[1].loaded) return fail(h, PG_ESTATE, "fine network weights not loaded (pg_load_weights)");
+    if (!h->emb_set[0] || !h->emb_set[1]) return fail(h, PG_ESTATE, "embedder state not set (pg_set_embedder)");
+    return PG_OK;
+}
+
+int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
+                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg) {
+    const int prec = h->cfg.precision;
+    int rc = ensure_stream(h, which, prec);
+    if (rc) return rc;
+    NetState& ns = h->net[which];
+    const bool fc = h->cfg.framecode_ch > 0;
+    if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
+    pgd::EvalArgs a{};
+    a.rays = rays; a.z = z; a.skts = skts; a.cams = cams;
+    a.codes = fc ? ns.d_codes : nullptr;
+    a.wstream = ns.d_stream[prec];
+    a.bias = ns.d_bias;
+    a.cutoff = h->d_cut;
+    a.raw = raw; a.dbg = dbg;
+    a.pose_stride = pose_stride;
+    a.n_points = n * S;
+    a.n_rays = (int)n;
+    a.S = S;
+    a.n_codes = ns.n_codes;
+    a.tau_v = h->tau[0];
+    a.tau_d = h->tau[1];
+    const bool sa = is_shape_a(prec);
+    const int pts = sa ? pg_eval16_points_per_pass() : pg_eval32_points_per_pass();
+    if (S < pts / (MAXR - 1))
+        return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
+    const long long iters = (a.n_points + pts - 1) / pts;
+    a.n_iters = (int)iters;
+    const int grid = (int)(iters < h->n_cu ? iters : h->n_cu);
+    int e = sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
+               : pg_launch_eval32(&a, prec, fc, grid, stream);
+    if (e) return fail(h, PG_EHIP, "fused embed+MLP kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pg_abi_version(void) { return PG_ABI_VERSION; }
+
+const char* pg_last_error(const pg_handle* h) { return h ? h->err : g_last_error; }
+
+int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_handle** out) {
+    if (!cfg || !out) return fail(nullptr, PG_EINVAL, "pg_create: null argument");
+    *out = nullptr;
+    if (n_devices != 1) return fail(nullptr, PG_EINVAL, "pg_create: n_devices must be 1 (one process per GPU), got %d", n_devices);
+    if (cfg->n_joints != J || cfg->multires != LV || cfg->multires_views != LD || cfg->multires_bones != 0 ||
+        cfg->net_depth != DEPTH || cfg->net_width != W || cfg->skip_layer != SKIP || cfg->view_width != VW ||
+        (cfg->framecode_ch != 0 && cfg->framecode_ch != FC_CH))
+        return fail(nullptr, PG_EINVAL,
+                    "pg_create: unsupported architecture (kernels are built for 24 joints, multires 7/4/0, "
+                    "8x256 trunk, skip 4, view width 128, frame code 0|16)");
+    if (cfg->precision < 0 || cfg->precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
+    if (cfg->chunk <= 0) return fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
+    if (!(cfg->density_scale > 0.f)) return fail(nullptr, PG_EINVAL, "pg_create: density_scale must be positive");
+    pg_handle* h = new (std::nothrow) pg_handle();
+    if (!h) return fail(nullptr, PG_ENOMEM, "pg_create: out of host memory");
+    h->cfg = *cfg;
+    h->device = device_ids ? device_ids[0] : 0;
+    for (int i = 0; i < 48; ++i) h->cut[i] = cfg->cutoff_dist;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { delete h; return fail(nullptr, PG_EHIP, "pg_create: no HIP device available (%s)", hipGetErrorString(e)); }
+    if (h->device < 0 || h->device >= ndev) { delete h; return fail(nullptr, PG_EINVAL, "pg_create: device %d out of range (%d devices)", cfg ? device_ids ? device_ids[0] : 0 : 0, ndev); }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(h->device) != hipSuccess || hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, PG_EHIP, "pg_create: cannot query device");
+    }
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(reinterpret_cast<void**>(&h->d_cut), 48 * sizeof(float)) != hipSuccess) {
+        delete h;
+        return fail(nullptr, PG_ENOMEM, "pg_create: device allocation failed");
+    }
+    *out = h;
+    return PG_OK;
+}
+
+void pg_destroy(pg_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (NetState& ns : h->net) {
+        for (auto& p : ns.d_stream) if (p) (void)hipFree(p);
+        if (ns.d_bias) (void)hipFree(ns.d_bias);
+        if (ns.d_codes) (void)hipFree(ns.d_codes);
+    }
+    if (h->d_cut) (void)hipFree(h->d_cut);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+}
+
+int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const int64_t* shapes, int n_tensors) {
+    if (!h || !tensors || !shapes) return fail(h, PG_EINVAL, "pg_load_weights: null argument");
+    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_load_weights: which_net must be 0 or 1");
+    if (n_tensors != 24) return fail(h, PG_EINVAL, "pg_load_weights: expected 24 tensors, got %d", n_tensors);
+    const int vcols = W + CH_D + h->cfg.framecode_ch;
+    int64_t want[24][2];
+    for (int l = 0; l < DEPTH; ++l) {
+        want[2 * l][0] = W; want[2 * l][1] = l == 0 ? CH_X : (l == SKIP + 1 ? CH_X + W : W);
+        want[2 * l + 1][0] = W; want[2 * l + 1][1] = 1;
+    }
+    want[16][0] = 1; want[16][1] = W;       want[17][0] = 1; want[17][1] = 1;
+    want[18][0] = W; want[18][1] = W;       want[19][0] = W; want[19][1] = 1;
+    want[20][0] = VW; want[20][1] = vcols;  want[21][0] = VW; want[21][1] = 1;
+    want[22][0] = 3; want[22][1] = VW;      want[23][0] = 3; want[23][1] = 1;
+    for (int i = 0; i < 24; ++i) {
+        if (!tensors[i]) return fail(h, PG_EINVAL, "pg_load_weights: tensor %d is null", i);
+        if (shapes[2 * i] != want[i][0] || shapes[2 * i + 1] != want[i][1])
+            return fail(h, PG_EINVAL, "pg_load_weights: tensor %d has shape [%lld,%lld], expected [%lld,%lld]", i,
+                        (long long)shapes[2 * i], (long long)shapes[2 * i + 1], (long long)want[i][0], (long long)want[i][1]);
+    }
+    NetState& ns = h->net[which];
+    ns.host.assign(24, {});
+    for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + want[i][0] * want[i][1]);
+    ns.loaded = true;
+    PG_HIP(h, hipSetDevice(h->device));
+    for (int p = 0; p < PG_PREC_COUNT; ++p)
+        if (ns.d_stream[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p])); ns.d_stream[p] = nullptr; }
+    std::vector<float> bias;
+    pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
+    if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
+    PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    return ensure_stream(h, which, h->cfg.precision);
+}
+
+int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_embedder: null handle");
+    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_set_embedder: which must be 0 (embed_fn) or 1 (embeddirs_fn)");
+    if (cutoff_dist) std::memcpy(h->cut + 24 * which, cutoff_dist, 24 * sizeof(float));
+    h->tau[which] = tau;
+    h->emb_set[which] = true;
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipMemcpy(h->d_cut, h->cut, sizeof h->cut, hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) {
+    if (!h || !codes) return fail(h, PG_EINVAL, "pg_set_framecodes: null argument");
+    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_set_framecodes: which_net must be 0 or 1");
+    if (h->cfg.framecode_ch != FC_CH) return fail(h, PG_EINVAL, "pg_set_framecodes: handle was created without frame codes");
+    if (n_codes <= 0) return fail(h, PG_EINVAL, "pg_set_framecodes: n_codes must be positive");
+    NetState& ns = h->net[which];
+    ns.codes_host.assign(codes, codes + (size_t)n_codes * FC_CH);
+    ns.codes_host.resize((size_t)(n_codes + 1) * FC_CH, 0.f);
+    for (int c = 0; c < FC_CH; ++c) {       // mean row (embedding.py:25-26), summed in row order
+        float s = 0.f;
+        for (int i = 0; i < n_codes; ++i) s += codes[(size_t)i * FC_CH + c];
+        ns.codes_host[(size_t)n_codes * FC_CH + c] = s / (float)n_codes;
+    }
+    ns.n_codes = n_codes;
+    PG_HIP(h, hipSetDevice(h->device));
+    if (ns.d_codes) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_codes)); ns.d_codes = nullptr; }
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_codes), ns.codes_host.size() * sizeof(float)));
+    PG_HIP(h, hipMemcpy(ns.d_codes, ns.codes_host.data(), ns.codes_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+int pg_set_precision(pg_handle* h, int precision) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_precision: null handle");
+    if (precision < 0 || precision >= PG_PREC_COUNT) return fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
+    h->cfg.precision = precision;
+    for (int w = 0; w < 2; ++w)
+        if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision); if (rc) return rc; }
+    return PG_OK;
+}
+
+int pg_set_chunk(pg_handle* h, int chunk) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_chunk: null handle");
+    if (chunk <= 0) return fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
+    h->cfg.chunk = chunk;
+    return PG_OK;
+}
+
+int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_query: null handle");
+    if (precision < 0 || precision >= PG_PREC_COUNT) return PG_EINVAL;
+    const bool fc = h->cfg.framecode_ch > 0;
+    const bool sa = is_shape_a(precision);
+    if (stream_bytes) *stream_bytes = (int64_t)(sa ? pgp::A::NCHUNK : pgp::B::NCHUNK) * CHUNK_BYTES;
+    if (mfma_per_group) {
+        const int64_t base = pgp::A::MFMA_PER_GROUP(fc);
+        *mfma_per_group = sa ? base : (precision == PG_PREC_FP32 ? base * 8 : base * 3);
+    }
+    return PG_OK;
+}
+
+int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* cyls,
+                           int64_t cyl_stride, int n_samples, int flags, float* near_far, float* z) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (n < 0 || !ray_batch || !cyls || !near_far || !z) return fail(h, PG_EINVAL, "pg_stage_sample_coarse: null/negative argument");
+    if (n_samples < 2) return fail(h, PG_EINVAL, "pg_stage_sample_coarse: N_samples must be >= 2");
+    if (cyl_stride != 0 && cyl_stride != 5) return fail(h, PG_EINVAL, "cyl_stride must be 0 or 5");
+    PG_HIP(h, hipSetDevice(h->device));
+    int e = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, n_samples,
+                                    (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, stream);
+    if (e) return fail(h, PG_EHIP, "sample_coarse launch failed: %s", hipGetErrorString((hipError_t)e));
+    return PG_OK;
+}
+
+int pg_stage_eval(pg_handle* h, void* stream, int which, int64_t n, int n_samples, const float* ray_batch,
+                  const float* z, const float* skts, int64_t pose_stride, const float* cams, float* raw, float* dbg) {
+    int rc = check_ready(h, which == 1);
+    if (rc) return rc;
+    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_stage_eval: which_net must be 0 or 1");
+    if (n < 0 || !ray_batch || !z || !skts || !raw) return fail(h, PG_EINVAL, "pg_stage_eval: null/negative argument");
+    if (pose_stride != 0 && pose_stride != 384) return fail(h, PG_EINVAL, "pose_stride must be 0 or 384");
+    if (n == 0) return PG_OK;
+    PG_HIP(h, hipSetDevice(h->device));
+    return launch_eval(h, stream, which, n, n_samples, ray_batch, z, skts, pose_stride, cams, raw, dbg);
+}
+
+int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, const float* ray_batch, const float* z,
+                       const float* raw, float* rgb, float* disp, float* acc, float* alpha, float* weights,
+                       int n_importance, float* z_fine) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (n < 0 || !ray_batch || !z || !raw) return fail(h, PG_EINVAL, "pg_stage_composite: null/negative argument");
+    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return fail(h, PG_EINVAL, "pg_stage_composite: N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
+    if (n_importance < 0 || n_importance > pg_composite_max_importance() || n_importance == 1)
+        return fail(h, PG_EINVAL, "pg_stage_composite: N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
+    if (n_importance > 0 && n_samples < 3) return fail(h, PG_EINVAL, "importance sampling needs N_samples >= 3");
+    PG_HIP(h, hipSetDevice(h->device));
+    int e = pg_launch_composite(ray_batch, z, raw, n, n_samples, h->cfg.density_scale, h->cfg.rgb_eps, rgb, disp, acc,
+                                alpha, weights, n_importance, z_fine, stream);
+    if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+    return PG_OK;
+}
+
+int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
+                   int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
+                   int n_importance, int flags, const pg_outputs* out) {
+    int rc = check_ready(h, n_importance > 0);
+    if (rc) return rc;
+    if (n < 0 || !ray_batch || !skts || !cyls || !out) return fail(h, PG_EINVAL, "pg_render_rays: null/negative argument");
+    if (pose_stride != 0 && pose_stride != 384) return fail(h, PG_EINVAL, "pose_stride must be 0 (shared) or 384 (per ray)");
+    if (cyl_stride != 0 && cyl_stride != 5) return fail(h, PG_EINVAL, "cyl_stride must be 0 (shared) or 5 (per ray)");
+    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return fail(h, PG_EINVAL, "N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
+    if (n_importance < 0 || n_importance == 1 || n_importance > pg_composite_max_importance())
+        return fail(h, PG_EINVAL, "N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
+    if (n_importance > 0 && n_samples + n_importance > pg_composite_max_samples())
+        return fail(h, PG_EINVAL, "N_samples + N_importance exceeds %d", pg_composite_max_samples());
+    if (n == 0) return PG_OK;
+    PG_HIP(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int S = n_samples, SF = n_samples + n_importance;
+    auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_nf = al((size_t)n * 2 * 4), b_zc = al((size_t)n * S * 4), b_rc = al((size_t)n * S * 16),
+                 b_w0 = al((size_t)n * S * 4), b_zf = al((size_t)n * SF * 4), b_rf = al((size_t)n * SF * 16);
+    rc = ensure_ws(h, b_nf + b_zc + b_rc + b_w0 + (n_importance > 0 ? b_zf + b_rf : 0));
+    if (rc) return rc;
+    uint8_t* p = h->ws;
+    float* nf = reinterpret_cast<float*>(p); p += b_nf;
+    float* zc = reinterpret_cast<float*>(p); p += b_zc;
+    float* rawc = reinterpret_cast<float*>(p); p += b_rc;
+    float* w0 = reinterpret_cast<float*>(p); p += b_w0;
+    float* zf = reinterpret_cast<float*>(p); p += b_zf;
+    float* rawf = reinterpret_cast<float*>(p);
+
+    rc = pg_stage_sample_coarse(h, stream, n, ray_batch, cyls, cyl_stride, S, flags, nf, zc);
+    if (rc) return rc;
+    rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr);
+    if (rc) return rc;
+    const bool hier = n_importance > 0;
+    int e = pg_launch_composite(ray_batch, zc, rawc, n, S, h->cfg.density_scale, h->cfg.rgb_eps,
+                                hier ? out->rgb0 : out->rgb_map, hier ? out->disp0 : out->disp_map,
+                                hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
+                                out->weights0 ? out->weights0 : w0, n_importance, hier ? zf : nullptr, stream);
+    if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (hier) {
+        rc = launch_eval(h, stream, 1, n, SF, ray_batch, zf, skts, pose_stride, cams, rawf, nullptr);
+        if (rc) return rc;
+        e = pg_launch_composite(ray_batch, zf, rawf, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, out->rgb_map,
+                                out->disp_map, out->acc_map, out->alpha, nullptr, 0, nullptr, stream);
+        if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    // optional intermediates
+    if (out->near_far) PG_HIP(h, hipMemcpyAsync(out->near_far, nf, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    if (out->z_coarse) PG_HIP(h, hipMemcpyAsync(out->z_coarse, zc, (size_t)n * S * 4, hipMemcpyDeviceToDevice, s));
+    if (out->raw_coarse) PG_HIP(h, hipMemcpyAsync(out->raw_coarse, rawc, (size_t)n * S * 16, hipMemcpyDeviceToDevice, s));
+    if (hier && out->z_fine) PG_HIP(h, hipMemcpyAsync(out->z_fine, zf, (size_t)n * SF * 4, hipMemcpyDeviceToDevice, s));
+    if (hier && out->raw_fine) PG_HIP(h, hipMemcpyAsync(out->raw_fine, rawf, (size_t)n * SF * 16, hipMemcpyDeviceToDevice, s));
+    return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+// pg_device.h -- device-side helpers shared by the fused embed+MLP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pg_program.h"
+
+namespace pgd {
+using namespace pgl;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Kernel arguments of one fused embed+MLP launch (one net, one pass).
+struct EvalArgs {
+    const float* rays;        // [n,11] ray_batch rows (o, d, near, far, viewdir): o,d used
+    const float* z;           // [n,S]  depths of the points p = o + d z
+    const float* skts;        // [*,24,4,4]
+    const float* cams;        // [n] frame-code index (float) or null
+    const float* codes;       // [n_codes+1,16], last row = mean code; null if no frame code
+    const uint8_t* wstream;   // packed weights (pg_pack.cpp)
+    const float* bias;        // BIAS_FLOATS
+    const float* cutoff;      // [48] = cutoff_dist of embed_fn (24) then embeddirs_fn (24)
+    float* raw;               // [n*S,4] (rgb_raw, sigma_raw)
+    float* dbg;               // [n*S,256] pre-activation of density layer 0, or null
+    long long pose_stride;    // floats between consecutive rays' skts (0 = shared pose)
+    long long n_points;       // n*S
+    int n_rays;
+    int S;
+    int n_codes;
+    int n_iters;              // workgroup passes = ceil(n_points / points per pass)
+    float tau_v, tau_d;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// Weight-stream consumer state of one wave: a 2-slot LDS ring of 16-KiB chunks filled by
+// LDS-DMA.  Every wave copies 16/NWAVE of the chunk's 1-KiB pieces; `enter(c)` is the
+// only synchronisation: own pieces landed (vmcnt 0) -> workgroup barrier -> chunk c is
+// readable by everyone, the other slot (chunk c-1) is free -> start chunk c+1 into it.
+template <int NWAVE, int NCHUNK_>
+struct Stream {
+    const uint8_t* wstream;
+    uint8_t* ring;
+    int wave, lane;
+    // Byte offset of the NEXT chunk to fetch.  Kept as loop-carried state on purpose:
+    // computed from the chunk index it would be a loop invariant per chunk, and hipcc
+    // hoists all NCHUNK 64-bit source addresses to kernel entry and spills them.
+    uint32_t next_off;
+    static constexpr int PER = 16 / NWAVE;
+
+    __device__ __forceinline__ void prefetch_next(int slot) {
+        const uint8_t* src = wstream + next_off + (wave * (PER * 1024) + lane * 16);
+        uint8_t* dst = ring + slot * CHUNK_BYTES + wave * (PER * 1024);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
+        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        asm volatile("" : "+s"(next_off));      // opaque: stops constant folding + hoisting
+    }
+    // kernel start: fetch chunk 0 into slot 0
+    __device__ __forceinline__ void start() { next_off = 0; prefetch_next(0); }
+    // entering chunk c (chunks are entered strictly in order 0..NCHUNK-1, 0, ...)
+    __device__ __forceinline__ void enter(int c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        prefetch_next((c + 1) & 1);
+    }
+    __device__ __forceinline__ const uint8_t* at(int c, int byte_off) const {
+        return ring + (c & 1) * CHUNK_BYTES + byte_off + lane * 16;
+    }
+};
+
+__device__ __forceinline__ f32x16 load_bias(const float* bias, int tile, int h) {
+    const float4* p = reinterpret_cast<const float4*>(bias + (tile * 2 + h) * 16);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
+}
+
+// LDS carve-up (bytes) shared by both kernel shapes
+constexpr int LDS_RING = 0;                                  // 2 x CHUNK_BYTES
+constexpr int LDS_BIAS = 2 * CHUNK_BYTES;                    // BIAS_FLOATS floats
+constexpr int LDS_CUT = LDS_BIAS + BIAS_FLOATS * 4;          // 48 floats
+constexpr int LDS_RTAB = LDS_CUT + 48 * 4;                   // MAXR slots
+constexpr int LDS_TOTAL = LDS_RTAB + MAXR * SLOT_FLOATS * 4;
+static_assert(LDS_BIAS % 16 == 0 && LDS_CUT % 16 == 0 && LDS_RTAB % 16 == 0, "LDS alignment");
+
+// q = (skt @ [p;1]).xyz with skt rows 0..2 at sk[0..11]      (core/encoders.py:8-23)
+__device__ __forceinline__ void bone_local(const float* sk, float px, float py, float pz,
+                                           float& qx, float& qy, float& qz) {
+    const float4 a = *reinterpret_cast<const float4*>(sk);
+    const float4 b = *reinterpret_cast<const float4*>(sk + 4);
+    const float4 c = *reinterpret_cast<const float4*>(sk + 8);
+    qx = fmaf(a.z, pz, fmaf(a.y, py, fmaf(a.x, px, a.w)));
+    qy = fmaf(b.z, pz, fmaf(b.y, py, fmaf(b.x, px, b.w)));
+    qz = fmaf(c.z, pz, fmaf(c.y, py, fmaf(c.x, px, c.w)));
+}
+
+// cutoff weight 1 - sigmoid(tau (v - c))                     (cutoff_embedder.py:139-146)
+__device__ __forceinline__ float cutoff_weight(float v, float tau, float c) {
+    const float t = tau * (v - c);
+    return 1.0f - 1.0f / (1.0f + expf(-t));
+}
+
+// The 18 density-input values of one joint for one point (RelDist + VecNorm + cutoff
+// embedding, encoders.py:101-122,172-193; cutoff_embedder.py:111-174):
+//   x[0] = v w, x[1+2f] = sin(2^f v) w, x[2+2f] = cos(2^f v) w (f < 7), x[15..17] = q/|q|
+// sin/cos of the octaves by exact angle doubling from one accurate sincosf.
+__device__ __forceinline__ void joint_values(const float* sk, float px, float py, float pz,
+                                             float tau, float cut, float* x) {
+    float qx, qy, qz;
+    bone_local(sk, px, py, pz, qx, qy, qz);
+    const float v = sqrtf(qx * qx + qy * qy + qz * qz);
+    const float w = cutoff_weight(v, tau, cut);
+    float s, c;
+    sincosf(v, &s, &c);
+    x[0] = v * w;
+#pragma unroll
+    for (int f = 0; f < LV; ++f) {
+        x[1 + 2 * f] = s * w;
+        x[2 + 2 * f] = c * w;
+        const float s2 = 2.0f * s * c;
+        c = (c - s) * (c + s);
+        s = s2;
+    }
+    const float den = fmaxf(v, 1e-12f);
+    x[15] = qx / den;
+    x[16] = qy / den;
+    x[17] = qz / den;
+}
+
+// distance of the point to one joint (for the view-embedding cutoff weight)
+__device__ __forceinline__ float joint_dist(const float* sk, float px, float py, float pz) {
+    float qx, qy, qz;
+    bone_local(sk, px, py, pz, qx, qy, qz);
+    return sqrtf(qx * qx + qy * qy + qz * qz);
+}
+
+// Fill the per-ray LDS table for the rays [r0, r0+nr) this pass touches.
+//  phase 1: skt rows, o, d, cam, frame code     phase 2 (after a barrier): view table
+template <int NTHREADS>
+__device__ __forceinline__ void ray_table_phase1(const EvalArgs& a, float* rtab, int r0, int nr) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < nr * 288; idx += NTHREADS) {
+        const int rr = idx / 288, k = idx - rr * 288;
+        const int j = k / 12, e = k - j * 12;
+        rtab[rr * SLOT_FLOATS + SLOT_SKT + k] = a.skts[(long long)(r0 + rr) * a.pose_stride + j * 16 + e];
+    }
+    for (int idx = tid; idx < nr * 24; idx += NTHREADS) {
+        const int rr = idx / 24, k = idx - rr * 24;
+        float* slot = rtab + rr * SLOT_FLOATS;
+        const long long ray = r0 + rr;
+        if (k < 6) {
+            slot[SLOT_O + k] = a.rays[ray * 11 + k];
+        } else if (k == 6) {
+            slot[SLOT_CAM] = a.cams ? a.cams[ray] : -1.0f;
+        } else if (k >= 8 && a.codes) {
+            const float cf = a.cams ? a.cams[ray] : -1.0f;
+            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
+            slot[SLOT_CODE + (k - 8)] = a.codes[ci * FC_CH + (k - 8)];
+        }
+    }
+}
+
+// View-direction table: e = normalize(R_j d) per joint (encoders.py:25-37,172-193), rows
+// (e, sin e, cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e | cos 8e) in D-sequence order.
+template <int NTHREADS>
+__device__ __forceinline__ void ray_table_phase2(float* rtab, int nr) {
+    for (int idx = threadIdx.x; idx < nr * J; idx += NTHREADS) {
+        const int rr = idx / J, j = idx - rr * J;
+        float* slot = rtab + rr * SLOT_FLOATS;
+        const float* sk = slot + SLOT_SKT + j * 12;
+        const float dx = slot[SLOT_D], dy = slot[SLOT_D + 1], dz = slot[SLOT_D + 2];
+        float e[3];
+        e[0] = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
+        e[1] = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
+        e[2] = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
+        const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
+        const int h = j / JH, jj = j - h * JH;
+        float* tab = slot + SLOT_DTAB + h * DSEQ;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ev = e[c] / den;
+            float s, co;
+            sincosf(ev, &s, &co);
+            float* m = tab + (jj * 3 + c) * 8;
+            m[0] = ev;
+#pragma unroll
+            for (int f = 0; f < LD; ++f) {
+                m[1 + 2 * f] = s;
+                if (f < LD - 1) m[2 + 2 * f] = co;
+                else tab[DSEQ_MAIN + jj * 3 + c] = co;
+                const float s2 = 2.0f * s * co;
+                co = (co - s) * (co + s);
+                s = s2;
+            }
+        }
+        if (jj == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tab[DSEQ_MAIN + JH * 3 + k] = 0.0f;
+        }
+    }
+}
+
+}  // namespace pgd

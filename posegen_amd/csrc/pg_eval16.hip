@@ -1,0 +1,269 @@
+// pg_eval16.hip -- fused bone-relative embedding + NeRF MLP, 16-bit MFMA operands
+// (bf16 or fp16, fp32 accumulate).  Shape A of pg_program.h.
+//
+// Replaces RayCaster.encode_inputs + run_network + NeRF.forward for one net
+// (reference core/raycasters.py:476-577, core/networks/nerf.py:90-148,
+// core/encoders.py, core/cutoff_embedder.py) on n*S points p = o + d*z.
+//
+// Workgroup = 8 waves (2 per SIMD), each wave owns 32 consecutive points of the
+// flattened [ray][sample] list and keeps their activations in registers across all
+// layers (pg_layout.h).  All 8 waves consume the same weight stream, staged
+// L2 -> LDS in 16-KiB chunks by global_load_lds_dwordx4 into a 2-slot ring (chunk c+1
+// in flight while chunk c feeds v_mfma_f32_32x32x16).  The 432-wide density input is
+// produced on the fly as B fragments (never stored) and recomputed for the skip layer;
+// the 648-wide view input is a per-ray sin/cos table in LDS times the per-point cutoff
+// weight.
+#include "pg_device.h"
+
+namespace pgd {
+using namespace pgp::A;
+
+constexpr int NWAVE = 8;
+constexpr int NTHR = NWAVE * 64;
+constexpr int PTS = NWAVE * 32;     // points per workgroup pass
+
+template <typename V> struct Op;
+template <> struct Op<bf16x8> {
+    static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ bf16x8 cvt(const float* x) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j];
+        return v;
+    }
+};
+template <> struct Op<f16x8> {
+    static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f16x8 cvt(const float* x) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)x[j];
+        return v;
+    }
+};
+
+using Stream16 = Stream<NWAVE, NCHUNK>;
+
+template <typename V>
+__device__ __forceinline__ V unit_of(Stream16& st, int c, int pos) {
+    return __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(c, pos * UNIT_BYTES)));
+}
+
+// one B fragment against NO out tiles, k-major segment starting at chunk cbase
+template <typename V, int NO>
+__device__ __forceinline__ void mma_row(f32x16* acc, Stream16& st, int cbase, int uu, V b) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int L = uu * NO + o;
+        if (L % UPC == 0) st.enter(cbase + L / UPC);
+        acc[o] = Op<V>::mfma(unit_of<V>(st, cbase + L / UPC, L % UPC), b, acc[o]);
+    }
+}
+
+// acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
+template <typename V>
+__device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, const float* slot,
+                                          const float* cut, float tau, float px, float py, float pz, int h) {
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+        float lo[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jj = 4 * sb + k;
+            float x[18];
+            joint_values(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
+            lo[2 * k] = x[16];
+            lo[2 * k + 1] = x[17];
+            mma_row<V, NT>(acc, st, cbase, sb * 9 + 2 * k, Op<V>::cvt(x));
+            mma_row<V, NT>(acc, st, cbase, sb * 9 + 2 * k + 1, Op<V>::cvt(x + 8));
+        }
+        mma_row<V, NT>(acc, st, cbase, sb * 9 + 8, Op<V>::cvt(lo));
+    }
+}
+
+template <typename V>
+__device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool relu) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+    f0 = Op<V>::cvt(t);
+    f1 = Op<V>::cvt(t + 8);
+}
+
+// fout = relu(W fin + b), out-tile-major segment of NT chunks starting at cbase
+template <typename V>
+__device__ __forceinline__ void hidden_layer(const V* fin, V* fout, Stream16& st, int cbase,
+                                             const float* bias, int tile0, int h) {
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+        st.enter(cbase + o);
+        f32x16 acc = load_bias(bias, tile0 + o, h);
+#pragma unroll
+        for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(unit_of<V>(st, cbase + o, u), fin[u], acc);
+        relu_pack<V>(acc, fout[2 * o], fout[2 * o + 1], true);
+    }
+}
+
+template <typename V, bool FC>
+__global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
+    float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
+    float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, pt = lane & 31;
+    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u};
+
+    for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
+    if (tid < 48) cut[tid] = a.cutoff[tid];
+    st.start();
+
+    for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        const long long p0 = (long long)it * PTS;
+        const long long plast = min(p0 + PTS - 1, a.n_points - 1);
+        const int r0 = (int)(p0 / a.S);
+        const int nr = (int)(plast / a.S) - r0 + 1;
+        __syncthreads();
+        ray_table_phase1<NTHR>(a, rtab, r0, nr);
+        __syncthreads();
+        ray_table_phase2<NTHR>(rtab, nr);
+        __syncthreads();
+
+        const long long gp = p0 + wave * 32 + pt;
+        const bool valid = gp < a.n_points;
+        const long long gpc = valid ? gp : a.n_points - 1;
+        const float* slot = rtab + ((int)(gpc / a.S) - r0) * SLOT_FLOATS;
+        const float zz = a.z[gpc];
+        // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
+        const float px = __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
+        const float py = __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
+        const float pz = __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
+
+        V fa[HU], fb[HU];
+        {   // ---- layer 0: K = 432 generated on the fly, all 8 out tiles live ----
+            f32x16 acc[NT];
+#pragma unroll
+            for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
+            x_segment<V>(acc, st, C_L0, slot, cut, a.tau_v, px, py, pz, h);
+            if (a.dbg && valid) {
+#pragma unroll
+                for (int o = 0; o < NT; ++o)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a.dbg[gp * W + 32 * o + rho(r, h)] = acc[o][r];
+            }
+#pragma unroll
+            for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fa[2 * o], fa[2 * o + 1], true);
+        }
+        // ---- layers 1..4 ----
+        hidden_layer<V>(fa, fb, st, C_L1 + 0 * CH_HID, bias, BT_LAYER0 + 1 * NT, h);
+        hidden_layer<V>(fb, fa, st, C_L1 + 1 * CH_HID, bias, BT_LAYER0 + 2 * NT, h);
+        hidden_layer<V>(fa, fb, st, C_L1 + 2 * CH_HID, bias, BT_LAYER0 + 3 * NT, h);
+        hidden_layer<V>(fb, fa, st, C_L1 + 3 * CH_HID, bias, BT_LAYER0 + 4 * NT, h);
+        {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
+            f32x16 acc[NT];
+#pragma unroll
+            for (int o = 0; o < NT; ++o) {
+                st.enter(C_L5H + o);
+                acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
+#pragma unroll
+                for (int u = 0; u < HU; ++u) acc[o] = Op<V>::mfma(unit_of<V>(st, C_L5H + o, u), fa[u], acc[o]);
+            }
+            x_segment<V>(acc, st, C_L5X, slot, cut, a.tau_v, px, py, pz, h);
+#pragma unroll
+            for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fb[2 * o], fb[2 * o + 1], true);
+        }
+        hidden_layer<V>(fb, fa, st, C_L6 + 0 * CH_HID, bias, BT_LAYER0 + 6 * NT, h);
+        hidden_layer<V>(fa, fb, st, C_L6 + 1 * CH_HID, bias, BT_LAYER0 + 7 * NT, h);
+        // ---- heads: feature (no activation) and sigma ----
+        float sigma;
+#pragma unroll
+        for (int o = 0; o < NT + 1; ++o) {
+            st.enter(C_FA + o);
+            f32x16 acc = load_bias(bias, BT_FEAT + o, h);      // tile 8 = BT_ALPHA
+#pragma unroll
+            for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(unit_of<V>(st, C_FA + o, u), fb[u], acc);
+            if (o < NT) relu_pack<V>(acc, fa[2 * o], fa[2 * o + 1], false);
+            else sigma = acc[0];
+        }
+        // ---- view layer: [feature(256), xd(648) (, code16)] -> 128, relu ----
+        V fg[HU / 2];
+        {
+            f32x16 acc[NTV];
+#pragma unroll
+            for (int o = 0; o < NTV; ++o) {
+                st.enter(C_VF + o);
+                acc[o] = load_bias(bias, BT_VIEW + o, h);
+#pragma unroll
+                for (int u = 0; u < HU; ++u) acc[o] = Op<V>::mfma(unit_of<V>(st, C_VF + o, u), fa[u], acc[o]);
+            }
+            float wd[JH];
+#pragma unroll
+            for (int jj = 0; jj < JH; ++jj)
+                wd[jj] = cutoff_weight(joint_dist(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
+                                       a.tau_d, cut[J + JH * h + jj]);
+            const float* tab = slot + SLOT_DTAB + h * DSEQ;
+#pragma unroll
+            for (int uu = 0; uu < DU; ++uu) {
+                const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
+                const float4 t1 = *reinterpret_cast<const float4*>(tab + uu * 8 + 4);
+                float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = uu < JH * 3 ? uu / 3 : (8 * (uu - JH * 3) + e) / 3;
+                    x[e] = k < JH ? x[e] * wd[k] : 0.0f;
+                }
+                mma_row<V, NTV>(acc, st, C_VD, uu, Op<V>::cvt(x));
+            }
+            if (FC) {
+                const float4 t0 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h);
+                const float4 t1 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h + 4);
+                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                mma_row<V, NTV>(acc, st, C_VD, DU, Op<V>::cvt(x));
+            }
+#pragma unroll
+            for (int o = 0; o < NTV; ++o) relu_pack<V>(acc[o], fg[2 * o], fg[2 * o + 1], true);
+        }
+        // ---- rgb head ----
+        st.enter(C_RGB);
+        f32x16 acc = load_bias(bias, BT_RGB, h);
+#pragma unroll
+        for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(unit_of<V>(st, C_RGB, u), fg[u], acc);
+        // chunk C_RGB+1 (= NCHUNK-1) is padding: step through it so that chunk 0 of the
+        // next pass is prefetched into ring slot 0 with the usual protocol
+        st.enter(C_RGB + 1);
+        if (valid && h == 0)
+            *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(acc[0], acc[1], acc[2], sigma);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename V, bool FC>
+static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
+    auto k = eval16_kernel<V, FC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace pgd
+
+extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream) {
+    using namespace pgd;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (fp16) e = framecode ? launch_eval16<f16x8, true>(*a, grid, s) : launch_eval16<f16x8, false>(*a, grid, s);
+    else      e = framecode ? launch_eval16<bf16x8, true>(*a, grid, s) : launch_eval16<bf16x8, false>(*a, grid, s);
+    return (int)e;
+}
+
+extern "C" int pg_eval16_points_per_pass(void) { return pgd::PTS; }

@@ -1,0 +1,320 @@
+// pg_kernels.hip -- the non-MLP kernels of the render path:
+//   sample_coarse_kernel : ray/cylinder near-far + per-chunk nanmean patch + coarse depths
+//   composite_kernel     : wave-per-ray prefix-product alpha compositing and the
+//                          deterministic inverse-CDF importance samples + sorted merge
+// All fp32.  These are HBM-bound byte movers: one coalesced pass over their inputs.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace pgk {
+
+// ------------------------------------------------------------------------------------
+// get_near_far_in_cylinder + sample_from_lineseg
+// (reference core/utils/ray_utils.py:292-344 and :204-251, eval mode: perturb = 0).
+// One workgroup per `chunk` consecutive rays, because rays that miss the cylinder take
+// the nanmean of the hits OF THEIR CHUNK (the reference calls this once per
+// batchify_rays slice, core/trainer.py:64-81).
+// ------------------------------------------------------------------------------------
+constexpr int SC_THREADS = 256;
+
+__device__ __forceinline__ void ray_near_far(const float* rb, const float* cyl, float& nn, float& ff,
+                                             bool& q_nan) {
+    const float ox = rb[0], oz = rb[2], dx = rb[3], dz = rb[5];
+    const float near0 = rb[6], far0 = rb[7];
+    // r_near = (o + d*near)[x,z], r_far = (o + d*far)[x,z]   (mul, then add)
+    const float nx = __fadd_rn(ox, __fmul_rn(dx, near0)), nz = __fadd_rn(oz, __fmul_rn(dz, near0));
+    const float fx = __fadd_rn(ox, __fmul_rn(dx, far0)), fz = __fadd_rn(oz, __fmul_rn(dz, far0));
+    const float radius = cyl[2];
+    const float cx = __fsub_rn(cyl[0], nx), cz = __fsub_rn(cyl[1], nz);     // near -> centre
+    const float sx = __fsub_rn(fx, nx), sz = __fsub_rn(fz, nz);             // near -> far
+    const float seg = __fsqrt_rn(__fadd_rn(__fmul_rn(sx, sx), __fmul_rn(sz, sz)));
+    const float scale = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dz, dz)));
+    const float cross = __fsub_rn(__fmul_rn(cx, sz), __fmul_rn(cz, sx));
+    const float dist = __fdiv_rn(fabsf(cross), seg);
+    const float q2 = __fsub_rn(__fmul_rn(radius, radius), __fmul_rn(dist, dist));
+    const float Q = q2 < 0.0f ? __builtin_nanf("") : __fsqrt_rn(q2);       // pow(0.5) of <0 is NaN
+    const float K = __fdiv_rn(__fadd_rn(__fmul_rn(cx, sx), __fmul_rn(cz, sz)), seg);
+    const float inside = (Q < K) ? 1.0f : 0.0f;
+    nn = __fadd_rn(near0, __fdiv_rn(__fmul_rn(inside, __fsub_rn(K, Q)), scale));
+    ff = __fadd_rn(near0, __fdiv_rn(__fadd_rn(K, Q), scale));
+    q_nan = isnan(Q);
+}
+
+__global__ __launch_bounds__(SC_THREADS) void sample_coarse_kernel(
+        const float* __restrict__ rays, const float* __restrict__ cyls, long long cyl_stride,
+        long long n, int chunk, int S, int lindisp,
+        float* __restrict__ near_far, float* __restrict__ z) {
+    __shared__ double red[3][SC_THREADS / 64][2];
+    __shared__ float fix[2];
+    __shared__ int any_nan;
+    const long long c0 = (long long)blockIdx.x * chunk;
+    const long long c1 = min(c0 + chunk, n);
+    const int tid = threadIdx.x;
+    if (tid == 0) any_nan = 0;
+    __syncthreads();
+
+    // pass 1: near/far, sums of the non-NaN entries (np.nanmean over the chunk)
+    double s_near = 0.0, s_far = 0.0, c_near = 0.0, c_far = 0.0;
+    bool saw_nan = false;
+    for (long long r = c0 + tid; r < c1; r += SC_THREADS) {
+        float nn, ff;
+        bool qn;
+        ray_near_far(rays + r * 11, cyls + r * cyl_stride, nn, ff, qn);
+        near_far[r * 2 + 0] = nn;
+        near_far[r * 2 + 1] = ff;
+        if (!isnan(nn)) { s_near += nn; c_near += 1.0; } else saw_nan = true;
+        if (!isnan(ff)) { s_far += ff; c_far += 1.0; }
+    }
+    if (saw_nan) any_nan = 1;
+    // block reduction (wave shuffle, then across the 4 waves)
+    double v[6] = {s_near, c_near, s_far, c_far, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) {
+        red[0][wave][0] = v[0]; red[0][wave][1] = v[1];
+        red[1][wave][0] = v[2]; red[1][wave][1] = v[3];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sn = 0, cn = 0, sf = 0, cf = 0;
+        for (int w = 0; w < SC_THREADS / 64; ++w) {
+            sn += red[0][w][0]; cn += red[0][w][1];
+            sf += red[1][w][0]; cf += red[1][w][1];
+        }
+        fix[0] = cn > 0 ? (float)(sn / cn) : __builtin_nanf("");
+        fix[1] = cf > 0 ? (float)(sf / cf) : __builtin_nanf("");
+    }
+    __syncthreads();
+    const bool patch = any_nan != 0;            // `if torch.isnan(new_near).any()`
+    const float m_near = fix[0], m_far = fix[1];
+
+    // pass 2: patch misses (rows where Q is NaN) and emit the S depths of every ray
+    const float step = 1.0f / (float)(S - 1);
+    for (long long r = c0 + tid; r < c1; r += SC_THREADS) {
+        float nn, ff;
+        bool qn;
+        ray_near_far(rays + r * 11, cyls + r * cyl_stride, nn, ff, qn);
+        if (patch && qn) {
+            nn = isnan(m_near) ? rays[r * 11 + 6] : m_near;
+            ff = isnan(m_far) ? rays[r * 11 + 7] : m_far;
+            near_far[r * 2 + 0] = nn;
+            near_far[r * 2 + 1] = ff;
+        }
+        float* zr = z + r * S;
+        for (int s = 0; s < S; ++s) {
+            // torch.linspace(0,1,S): start + i*step below the midpoint, end - (S-1-i)*step above
+            const float t = s < S / 2 ? __fmul_rn(step, (float)s) : __fsub_rn(1.0f, __fmul_rn(step, (float)(S - 1 - s)));
+            float zv;
+            if (!lindisp) {
+                zv = __fadd_rn(__fmul_rn(nn, __fsub_rn(1.0f, t)), __fmul_rn(ff, t));
+            } else {
+                const float a = __fmul_rn(__fdiv_rn(1.0f, nn), __fsub_rn(1.0f, t));
+                const float b = __fmul_rn(__fdiv_rn(1.0f, ff), t);
+                zv = __fdiv_rn(1.0f, __fadd_rn(a, b));
+            }
+            zr[s] = zv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// raw2outputs (reference core/networks/nerf.py:150-205, eval: no noise) and, when
+// n_imp > 0, isample_from_lineseg / sample_pdf with det=True
+// (core/utils/ray_utils.py:157-201, 255-289).  One wave per ray; sample s lives in lane
+// s / E, E = ceil(S/64) consecutive samples per lane; transmittance is an exclusive
+// prefix product (lane-local then a 6-step wave scan).
+// ------------------------------------------------------------------------------------
+constexpr int CP_WAVES = 4;
+constexpr int CP_MAXE = 4;          // S <= 256
+constexpr int CP_MAXS = 64 * CP_MAXE;
+constexpr int CP_MAXI = 64;         // importance samples per ray
+
+// LDS written by some lanes of a wave is read by other lanes of the SAME wave: the LDS
+// unit serves one wave's accesses in order, so only compiler reordering must be fenced.
+#define PG_WAVE_SYNC()                                               \
+    do {                                                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       \
+        __builtin_amdgcn_wave_barrier();                             \
+    } while (0)
+
+__device__ __forceinline__ float wave_excl_scan_mul(float x, int lane) {
+    // inclusive Hillis-Steele product, then shift by one lane
+    float incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        if (lane >= off) incl *= t;
+    }
+    const float prev = __shfl_up(incl, 1);
+    return lane == 0 ? 1.0f : prev;
+}
+__device__ __forceinline__ float wave_incl_scan_add(float x, int lane) {
+    float incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    return incl;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+__global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
+        const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ raw,
+        long long n, int S, float density_scale, float rgb_eps,
+        float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+        float* __restrict__ alpha_out, float* __restrict__ w_out,
+        int n_imp, float* __restrict__ z_fine) {
+    __shared__ float sh_w[CP_WAVES][CP_MAXS];
+    __shared__ float sh_z[CP_WAVES][CP_MAXS + CP_MAXI];
+    __shared__ float sh_cdf[CP_WAVES][CP_MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * CP_WAVES + wave;
+    if (ray >= n) return;                       // wave-uniform; no block barriers below
+    const int E = (S + 63) >> 6;
+    const float* rb = rays + ray * 11;
+    const float dnorm = sqrtf(rb[3] * rb[3] + rb[4] * rb[4] + rb[5] * rb[5]);
+    const float* zr = z + ray * S;
+    const float4* rr = raw + ray * S;
+
+    float a_[CP_MAXE], z_[CP_MAXE], cr[CP_MAXE], cg[CP_MAXE], cb[CP_MAXE];
+    float lane_prod = 1.0f;
+#pragma unroll
+    for (int e = 0; e < CP_MAXE; ++e) {
+        const int s = lane * E + e;
+        a_[e] = 0.0f; z_[e] = 0.0f; cr[e] = cg[e] = cb[e] = 0.0f;
+        if (e < E && s < S) {
+            const float4 q = rr[s];
+            const float zs = zr[s];
+            const float delta = (s + 1 < S ? zr[s + 1] - zs : 1e10f) * dnorm;
+            const float sig = fmaxf(q.w / density_scale + 0.0f, 0.0f);
+            a_[e] = 1.0f - expf(-sig * delta);
+            z_[e] = zs;
+            const float k = 1.0f + 2.0f * rgb_eps;
+            cr[e] = (1.0f / (1.0f + expf(-q.x))) * k - rgb_eps;
+            cg[e] = (1.0f / (1.0f + expf(-q.y))) * k - rgb_eps;
+            cb[e] = (1.0f / (1.0f + expf(-q.z))) * k - rgb_eps;
+            lane_prod *= (1.0f - a_[e] + 1e-10f);
+        }
+    }
+    float T = wave_excl_scan_mul(lane_prod, lane);
+    float sr = 0, sg = 0, sb = 0, sd = 0, sw = 0;
+#pragma unroll
+    for (int e = 0; e < CP_MAXE; ++e) {
+        const int s = lane * E + e;
+        if (e < E && s < S) {
+            const float w = a_[e] * T;
+            T *= (1.0f - a_[e] + 1e-10f);
+            sr += w * cr[e]; sg += w * cg[e]; sb += w * cb[e];
+            sd += w * z_[e]; sw += w;
+            if (alpha_out) alpha_out[ray * S + s] = a_[e];
+            if (w_out) w_out[ray * S + s] = w;
+            sh_w[wave][s] = w;
+            sh_z[wave][s] = z_[e];
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sw = wave_sum(sw);
+    if (lane == 0) {
+        if (rgb_out) { rgb_out[ray * 3 + 0] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+        if (disp_out) {
+            float disp = 1.0f / fmaxf(1e-10f, sd / (sw + 1e-10f));
+            // invalid_mask: torch.isclose(sum w, 0) with default rtol/atol -> |sum w| <= 1e-8
+            if (fabsf(sw) <= 1e-8f) disp = 0.0f;
+            disp_out[ray] = disp;
+        }
+        if (acc_out) acc_out[ray] = fminf(sw, 1.0f);
+    }
+    if (n_imp <= 0 || z_fine == nullptr) return;
+
+    // ---- importance samples: pdf over the S-2 interior weights, bins = S-1 midpoints ----
+    PG_WAVE_SYNC();
+    const int NB = S - 2;                       // number of pdf entries; cdf has NB+1 = S-1 entries
+    float pw[CP_MAXE];
+    float part = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CP_MAXE; ++e) {
+        const int i = lane * E + e;
+        pw[e] = 0.0f;
+        if (e < E && i < NB) { pw[e] = sh_w[wave][i + 1] + 1e-5f; part += pw[e]; }
+    }
+    const float total = wave_sum(part);
+    // cdf[0] = 0, cdf[i+1] = cumsum(pdf)[i]
+    float lane_sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CP_MAXE; ++e) { pw[e] = pw[e] / total; lane_sum += pw[e]; }
+    float run = wave_incl_scan_add(lane_sum, lane) - lane_sum;
+    if (lane == 0) sh_cdf[wave][0] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CP_MAXE; ++e) {
+        const int i = lane * E + e;
+        if (e < E && i < NB) { run += pw[e]; sh_cdf[wave][i + 1] = run; }
+    }
+    PG_WAVE_SYNC();
+    const int NC = NB + 1;
+    for (int k = lane; k < n_imp; k += 64) {
+        // torch.linspace(0,1,n_imp)
+        const float stepu = 1.0f / (float)(n_imp - 1);
+        const float u = k < n_imp / 2 ? stepu * (float)k : 1.0f - stepu * (float)(n_imp - 1 - k);
+        // searchsorted(cdf, u, right=True): first index with cdf > u
+        int lo = 0, hi = NC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sh_cdf[wave][mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, NC - 1);
+        const float c0 = sh_cdf[wave][below], c1 = sh_cdf[wave][above];
+        const float b0 = 0.5f * (sh_z[wave][below + 1] + sh_z[wave][below]);
+        const float b1 = 0.5f * (sh_z[wave][above + 1] + sh_z[wave][above]);
+        float den = c1 - c0;
+        if (den < 1e-5f) den = 1.0f;
+        const float t = (u - c0) / den;
+        sh_z[wave][S + k] = b0 + t * (b1 - b0);
+    }
+    PG_WAVE_SYNC();
+    // ---- stable merge of the S + n_imp depths by rank (== torch.sort of the concat) ----
+    const int NTOT = S + n_imp;
+    for (int i = lane; i < NTOT; i += 64) {
+        const float x = sh_z[wave][i];
+        int rank = 0;
+        for (int j = 0; j < NTOT; ++j) {
+            const float y = sh_z[wave][j];
+            rank += (y < x || (y == x && j < i)) ? 1 : 0;
+        }
+        z_fine[ray * NTOT + rank] = x;
+    }
+}
+
+}  // namespace pgk
+
+extern "C" int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride,
+                                       long long n, int chunk, int S, int lindisp,
+                                       float* near_far, float* z, void* stream) {
+    if (n <= 0) return 0;
+    const long long blocks = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(pgk::sample_coarse_kernel, dim3((unsigned)blocks), dim3(pgk::SC_THREADS), 0,
+                       static_cast<hipStream_t>(stream), rays, cyls, cyl_stride, n, chunk, S, lindisp,
+                       near_far, z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
+                                   float density_scale, float rgb_eps, float* rgb, float* disp, float* acc,
+                                   float* alpha, float* weights, int n_imp, float* z_fine, void* stream) {
+    if (n <= 0) return 0;
+    const long long blocks = (n + pgk::CP_WAVES - 1) / pgk::CP_WAVES;
+    hipLaunchKernelGGL(pgk::composite_kernel, dim3((unsigned)blocks), dim3(pgk::CP_WAVES * 64), 0,
+                       static_cast<hipStream_t>(stream), rays, z, reinterpret_cast<const float4*>(raw), n, S,
+                       density_scale, rgb_eps, rgb, disp, acc, alpha, weights, n_imp, z_fine);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_composite_max_samples(void) { return pgk::CP_MAXS; }
+extern "C" int pg_composite_max_importance(void) { return pgk::CP_MAXI; }

@@ -1,0 +1,110 @@
+// pg_layout.h -- weight-stream / lane-value layouts shared by the host packer
+// (pg_pack.cpp) and the fused embed+MLP kernels (pg_eval*.hip).
+//
+// Design ("points on lanes, channels in registers"):
+//   Every layer is computed transposed, Y^T[out, pt] = W[out, k] * X^T[k, pt], with
+//   v_mfma_f32_32x32x{16_bf16,16_f16,2_f32}: A = weights (32 out-channels x K),
+//   B = activations (K x 32 points), C/D = 32 out-channels x 32 points.  The C/D
+//   layout puts the POINT on the lane (col = lane&31) and the out-channel in the
+//   register (row = (r&3) + 8*(r>>2) + 4*(lane>>5)), which is exactly the B-operand
+//   layout of the next layer up to a fixed permutation of k.  So a wave owns 32 points
+//   and carries their whole activation vector through all layers in registers: no
+//   LDS or cross-lane traffic for activations.  The k permutation is folded into the
+//   weights by the host packer, which emits the weights as a linear stream of 1-KiB
+//   "units" (64 lanes x 16 B = one A fragment) in the exact order the kernel consumes
+//   them; the kernel streams them L2 -> LDS with global_load_lds_dwordx4 (lane-linear,
+//   conflict-free ds_read_b128) and all waves of a workgroup share each unit.
+//
+// Reference semantics of the channels: SURVEY.md section 8 (a'), i.e.
+// core/cutoff_embedder.py:111-174 (channel = row*24+j / row*72+3j+c),
+// core/networks/nerf.py:94-148 (layer structure).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PG_HD __host__ __device__
+#else
+#define PG_HD
+#endif
+
+namespace pgl {
+
+constexpr int J = 24;            // joints
+constexpr int JH = 12;           // joints handled by one lane half (h = lane>>5)
+constexpr int LV = 7;            // multires (distance frequencies)
+constexpr int LD = 4;            // multires_views
+constexpr int ROWS_V = 1 + 2 * LV;   // 15
+constexpr int ROWS_D = 1 + 2 * LD;   // 9
+constexpr int CH_V = J * ROWS_V;     // 360
+constexpr int CH_R = J * 3;          // 72
+constexpr int CH_X = CH_V + CH_R;    // 432  density-net input
+constexpr int CH_D = J * 3 * ROWS_D; // 648  view input
+constexpr int W = 256;           // trunk width
+constexpr int NT = W / 32;       // 8 out tiles
+constexpr int VW = 128;          // view layer width
+constexpr int NTV = VW / 32;     // 4
+constexpr int DEPTH = 8;
+constexpr int SKIP = 4;          // concat after layer 4 -> layer 5 has K = 432+256
+constexpr int FC_CH = 16;        // frame code channels (when enabled)
+
+constexpr int CHUNK_BYTES = 16384;   // LDS ring slot = 16 units of 1 KiB
+constexpr int UNIT_BYTES = 1024;
+
+// lane-value sequences ------------------------------------------------------------
+// X: 216 values per lane half: three superblocks of 4 joints; per joint 16 values
+// (q = 0..15) then one leftover unit holding q = 16,17 of the 4 joints.
+//   q = 0: v*w   q = 1+2f: sin(2^f v)*w   q = 2+2f: cos(2^f v)*w   q = 15..17: r_xyz
+constexpr int XSEQ = 216;
+// D: 328 values per lane half: (jj,c) blocks of 8 (rows 0..7) then 36 leftovers
+// (row 8 = cos(8e)) and 4 zero pads.
+constexpr int DSEQ_MAIN = JH * 3 * 8;   // 288
+constexpr int DSEQ = DSEQ_MAIN + 40;    // 328
+constexpr int HSEQ = W / 2;             // 128 hidden values per lane half
+
+// row of a 32-row C/D tile held in accumulator register r by lane half h
+PG_HD constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Input column of the density-net input (0..431) for X-sequence index i of half h.
+PG_HD constexpr int xseq_channel(int i, int h) {
+    int sb = i / 72, w = i % 72;
+    int jj = 0, q = 0;
+    if (w < 64) { jj = 4 * sb + w / 16; q = w % 16; }
+    else        { jj = 4 * sb + (w - 64) / 2; q = 16 + (w - 64) % 2; }
+    int j = JH * h + jj;
+    return q < ROWS_V ? q * J + j : CH_V + 3 * j + (q - ROWS_V);
+}
+// View-embedding channel (0..647, -1 = zero pad) for D-sequence index i of half h.
+PG_HD constexpr int dseq_channel(int i, int h) {
+    if (i < DSEQ_MAIN) {
+        int blk = i / 8, row = i % 8;
+        int j = JH * h + blk / 3, c = blk % 3;
+        return row * (3 * J) + 3 * j + c;
+    }
+    int k = i - DSEQ_MAIN;
+    if (k >= JH * 3) return -1;
+    int j = JH * h + k / 3, c = k % 3;
+    return 8 * (3 * J) + 3 * j + c;
+}
+// Hidden channel for H-sequence index i (= 16*tile + r) of half h.
+PG_HD constexpr int hseq_channel(int i, int h) { return 32 * (i / 16) + rho(i % 16, h); }
+
+// per-ray LDS table slot (floats)
+constexpr int SLOT_SKT = 0;                 // 24 x 12: rows 0..2 of each 4x4 (R|t)
+constexpr int SLOT_DTAB = 288;              // 2 halves x DSEQ
+constexpr int SLOT_O = SLOT_DTAB + 2 * DSEQ;  // 944
+constexpr int SLOT_D = SLOT_O + 3;            // 947
+constexpr int SLOT_CAM = SLOT_D + 3;          // 950
+constexpr int SLOT_CODE = 952;                // 16 floats
+constexpr int SLOT_FLOATS = 976;              // multiple of 4
+constexpr int MAXR = 9;                       // rays overlapped by one workgroup pass
+
+// bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1)
+constexpr int BT_LAYER0 = 0;
+constexpr int BT_FEAT = 64;
+constexpr int BT_ALPHA = 72;
+constexpr int BT_VIEW = 73;
+constexpr int BT_RGB = 77;
+constexpr int BT_COUNT = 78;
+constexpr int BIAS_FLOATS = BT_COUNT * 32;   // [tile][h][r]
+
+}  // namespace pgl

@@ -1,0 +1,169 @@
+// pg_pack.cpp -- host-side packing of the reference's nn.Linear tensors into the
+// per-precision weight streams and the bias table the kernels consume.
+//
+// Input tensors follow the reference checkpoint layout (core/networks/nerf.py:57-88,
+// [out,in] row-major).  Output: a linear stream of A-operand units in the exact
+// consumption order of pg_program.h, with the k permutations of pg_layout.h folded in.
+#include "pg_pack.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace pgpack {
+using namespace pgp;
+
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;      // round-to-nearest-even
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+static inline float f16_to_f32(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+struct InUnits { int seq; int n_values; int colbase; };
+struct Segment {
+    int mat;          // MAT_*
+    int no;           // out tiles
+    bool kmajor;
+    std::vector<InUnits> inputs;
+};
+
+static int seq_channel(int seq, int i, int h) {
+    switch (seq) {
+        case SEQ_X: return xseq_channel(i, h);
+        case SEQ_H: return hseq_channel(i, h);
+        case SEQ_D: return dseq_channel(i, h);
+        case SEQ_CODE: return 8 * h + i;
+    }
+    return -1;
+}
+
+// weight element of matrix `mat`, out row `row`, input column `col` (0 outside)
+float NetTensors::w(int mat, int row, int col) const {
+    const float* p = nullptr;
+    int rows = 0, cols = 0;
+    if (mat >= MAT_L0 && mat < MAT_L0 + DEPTH) { p = lw[mat]; rows = W; cols = lcols[mat]; }
+    else if (mat == MAT_FEAT) { p = feat_w; rows = W; cols = W; }
+    else if (mat == MAT_ALPHA) { p = alpha_w; rows = 1; cols = W; }
+    else if (mat == MAT_VIEW) { p = view_w; rows = VW; cols = view_cols; }
+    else if (mat == MAT_RGB) { p = rgb_w; rows = 3; cols = VW; }
+    else if (mat == MAT_FEAT_ALPHA) {
+        if (row < W) { p = feat_w; rows = W; cols = W; }
+        else { p = alpha_w; rows = 1; cols = W; row -= W; }
+    }
+    if (!p || row < 0 || row >= rows || col < 0 || col >= cols) return 0.f;
+    return p[(size_t)row * cols + col];
+}
+
+static std::vector<Segment> program(int shape, bool fc) {
+    std::vector<Segment> s;
+    auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
+    const bool km = (shape == SHAPE_B);
+    s.push_back({MAT_L0, NT, true, {{SEQ_X, XSEQ, 0}}});
+    for (int l = 1; l <= 4; ++l) s.push_back({MAT_L0 + l, NT, km, {hid(0)}});
+    s.push_back({MAT_L0 + 5, NT, km, {hid(CH_X)}});
+    s.push_back({MAT_L0 + 5, NT, true, {{SEQ_X, XSEQ, 0}}});
+    for (int l = 6; l <= 7; ++l) s.push_back({MAT_L0 + l, NT, km, {hid(0)}});
+    if (shape == SHAPE_A) {
+        s.push_back({MAT_FEAT_ALPHA, NT + 1, false, {hid(0)}});
+    } else {
+        s.push_back({MAT_FEAT, NT, true, {hid(0)}});
+        s.push_back({MAT_ALPHA, 1, true, {hid(0)}});
+    }
+    s.push_back({MAT_VIEW, NTV, km, {hid(0)}});
+    {
+        Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
+        if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
+        s.push_back(v);
+    }
+    s.push_back({MAT_RGB, 1, km, {{SEQ_H, VW / 2, 0}}});
+    return s;
+}
+
+int pack_stream(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& out,
+                std::vector<int>* seg_chunk_base) {
+    const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A : SHAPE_B;
+    const bool is_f32 = precision == PG_PREC_FP32;
+    const bool is_bf = precision == PG_PREC_BF16 || precision == PG_PREC_BF16X3;
+    const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3;
+    if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
+    const int ue = is_f32 ? 4 : 8;
+    const size_t unit_bytes = split ? 2048 : 1024;
+    out.clear();
+    if (seg_chunk_base) seg_chunk_base->clear();
+    for (const Segment& sg : program(shape, fc)) {
+        if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
+        // flatten the input units of this segment
+        struct U { int seq, u, colbase; };
+        std::vector<U> us;
+        for (const InUnits& in : sg.inputs)
+            for (int u = 0; u < in.n_values / ue; ++u) us.push_back({in.seq, u, in.colbase});
+        const int nu = (int)us.size();
+        for (int L = 0; L < nu * sg.no; ++L) {
+            const int ui = sg.kmajor ? L / sg.no : L % nu;
+            const int o = sg.kmajor ? L % sg.no : L / nu;
+            const U& un = us[ui];
+            const size_t base = out.size();
+            out.resize(base + unit_bytes, 0);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 31, h = lane >> 5;
+                for (int e = 0; e < ue; ++e) {
+                    const int ch = seq_channel(un.seq, un.u * ue + e, h);
+                    const float wv = ch < 0 ? 0.f : t.w(sg.mat, 32 * o + row, un.colbase + ch);
+                    if (is_f32) {
+                        std::memcpy(&out[base + lane * 16 + e * 4], &wv, 4);
+                    } else {
+                        uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
+                        std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                        if (split) {
+                            const float rem = wv - (is_bf ? bf16_to_f32(hi) : f16_to_f32(hi));
+                            uint16_t lo = is_bf ? f32_to_bf16(rem) : f32_to_f16(rem);
+                            std::memcpy(&out[base + 1024 + lane * 16 + e * 2], &lo, 2);
+                        }
+                    }
+                }
+            }
+        }
+        out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
+    }
+    const size_t nchunk = shape == SHAPE_A ? A::NCHUNK : B::NCHUNK;
+    if (out.size() > nchunk * CHUNK_BYTES) return -2;
+    out.resize(nchunk * CHUNK_BYTES, 0);
+    return 0;
+}
+
+void pack_bias(const NetTensors& t, std::vector<float>& out) {
+    out.assign(BIAS_FLOATS, 0.f);
+    auto put = [&](int tile, const float* b, int n, int row0) {
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                int row = row0 + rho(r, h);
+                out[(size_t)(tile * 2 + h) * 16 + r] = (b && row < n) ? b[row] : 0.f;
+            }
+    };
+    for (int l = 0; l < DEPTH; ++l)
+        for (int o = 0; o < NT; ++o) put(BT_LAYER0 + l * NT + o, t.lb[l], W, 32 * o);
+    for (int o = 0; o < NT; ++o) put(BT_FEAT + o, t.feat_b, W, 32 * o);
+    put(BT_ALPHA, t.alpha_b, 1, 0);
+    for (int o = 0; o < NTV; ++o) put(BT_VIEW + o, t.view_b, VW, 32 * o);
+    put(BT_RGB, t.rgb_b, 3, 0);
+}
+
+}  // namespace pgpack

@@ -1,0 +1,32 @@
+// pg_pack.h -- host packer interface (see pg_pack.cpp)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/posegen_hip.h"
+#include "pg_program.h"
+
+namespace pgpack {
+
+enum { SHAPE_A = 0, SHAPE_B = 1 };
+
+// Borrowed host pointers to one net's tensors (reference checkpoint layout).
+struct NetTensors {
+    const float* lw[pgl::DEPTH] = {};
+    const float* lb[pgl::DEPTH] = {};
+    int lcols[pgl::DEPTH] = {};
+    const float* alpha_w = nullptr; const float* alpha_b = nullptr;
+    const float* feat_w = nullptr;  const float* feat_b = nullptr;
+    const float* view_w = nullptr;  const float* view_b = nullptr;
+    int view_cols = 0;
+    const float* rgb_w = nullptr;   const float* rgb_b = nullptr;
+    float w(int mat, int row, int col) const;
+};
+
+// Packs the weight stream for `precision`; returns 0, or <0 on an internal layout error.
+int pack_stream(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out,
+                std::vector<int>* seg_chunk_base = nullptr);
+void pack_bias(const NetTensors& t, std::vector<float>& out);
+
+}  // namespace pgpack

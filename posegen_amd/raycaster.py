@@ -1,0 +1,334 @@
+"""HIP-backed drop-in for the reference's `RayCaster` (core/raycasters.py:326-794).
+
+`HipRenderer` is a typed wrapper around one `pg_handle` (device memory and streams
+come from PyTorch-ROCm: plumbing only).  `HipRayCaster` is the duck-typed object the
+reference stores under ``render_kwargs['ray_caster']`` and calls at
+core/trainer.py:74: same call signature, same returned dict keys
+(`_collect_outputs`, raycasters.py:711-724), same checkpoint key scheme
+(`state_dict` / `load_state_dict`, raycasters.py:752-788).
+
+Inference (eval-mode, `perturb == 0`) only: training-mode arguments raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .config import PREC_BF16, PREC_BY_NAME, PREC_NAMES, RenderConfig
+
+NET_TENSOR_ORDER = ([f"pts_linears.{l}.{k}" for l in range(8) for k in ("weight", "bias")]
+                    + [f"{n}.{k}" for n in ("alpha_linear", "feature_linear", "views_linears.0", "rgb_linear")
+                       for k in ("weight", "bias")])
+
+
+def _np32(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+
+
+def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipRenderer:
+    """Owns a pg_handle on one HIP device."""
+
+    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+        if isinstance(precision, str):
+            precision = PREC_BY_NAME[precision]
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _ffi.HipLibraryError("HipRenderer needs a HIP device (torch device 'cuda:N'); "
+                                       "the render path has no CPU fallback")
+        self.lib = _ffi.load_library()
+        self.precision = int(precision)
+        pc = _ffi.PgConfig(n_joints=cfg.n_joints, multires=cfg.multires, multires_views=cfg.multires_views,
+                           multires_bones=cfg.multires_bones, net_depth=cfg.net_depth, net_width=cfg.net_width,
+                           skip_layer=cfg.skips[0], view_width=cfg.net_width // 2,
+                           framecode_ch=cfg.framecode_ch, n_framecodes=cfg.n_framecodes, chunk=cfg.chunk,
+                           precision=self.precision, cutoff_dist=cfg.cutoff_dist,
+                           density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps, reserved0=0.0)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        ids = (C.c_int * 1)(idx)
+        h = C.c_void_p()
+        rc = self.lib.pg_create(C.byref(pc), 1, ids, C.byref(h))
+        _ffi.check(self.lib, None, rc)
+        self.handle = h
+        self._state: Dict[str, dict] = {}
+        self._chunk = cfg.chunk
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        _ffi.check(self.lib, self.handle, rc)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- state ------------------------------------------------------------------------
+    def load_network(self, which: int, sd: Dict[str, np.ndarray]):
+        """which 0 = coarse ('network_fn_state_dict'), 1 = fine ('network_fine_state_dict')."""
+        arrs = [_np32(sd[k]) for k in NET_TENSOR_ORDER]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        shp = (C.c_int64 * (2 * len(arrs)))()
+        for i, a in enumerate(arrs):
+            shp[2 * i] = a.shape[0]
+            shp[2 * i + 1] = a.shape[1] if a.ndim == 2 else 1
+        self._check(self.lib.pg_load_weights(self.handle, which, ptrs, shp, len(arrs)))
+        if self.cfg.framecode_ch > 0:
+            codes = _np32(sd["framecodes.codes.weight"])
+            self._check(self.lib.pg_set_framecodes(self.handle, which, codes.ctypes.data, codes.shape[0]))
+        self._state["network_fn_state_dict" if which == 0 else "network_fine_state_dict"] = {
+            k: torch.from_numpy(_np32(v).copy()) for k, v in sd.items()}
+
+    def set_embedder(self, which: int, tau: float, cutoff_dist=None):
+        """which 0 = embed_fn, 1 = embeddirs_fn (cutoff_embedder.py:89-94)."""
+        cd = _np32(np.full(24, self.cfg.cutoff_dist) if cutoff_dist is None else cutoff_dist)
+        self._check(self.lib.pg_set_embedder(self.handle, which, cd.ctypes.data, float(tau)))
+        self._state["embed_state_dict" if which == 0 else "embeddirs_state_dict"] = {
+            "cutoff_dist": torch.from_numpy(cd.copy()), "tau": torch.tensor(float(tau))}
+
+    def set_precision(self, precision):
+        if isinstance(precision, str):
+            precision = PREC_BY_NAME[precision]
+        self._check(self.lib.pg_set_precision(self.handle, int(precision)))
+        self.precision = int(precision)
+
+    def set_chunk(self, chunk: int):
+        if int(chunk) != self._chunk:
+            self._check(self.lib.pg_set_chunk(self.handle, int(chunk)))
+            self._chunk = int(chunk)
+
+    def query(self, precision=None):
+        sb, mf = C.c_int64(), C.c_int64()
+        self._check(self.lib.pg_query(self.handle, self.precision if precision is None else int(precision),
+                                      C.byref(sb), C.byref(mf)))
+        return {"stream_bytes": sb.value, "mfma_per_group": mf.value}
+
+    # -- the hot path -----------------------------------------------------------------
+    def _pose_args(self, skts: torch.Tensor, n: int):
+        """[1|n,24,4,4] -> (contiguous device tensor, stride in floats)."""
+        if skts.dim() == 3:
+            skts = skts[None]
+        if skts.shape[0] == 1 or skts.stride(0) == 0:
+            return _dev_f32(skts[:1], self.device), 0
+        if skts.shape[0] != n:
+            raise ValueError(f"skts has {skts.shape[0]} poses for {n} rays")
+        return _dev_f32(skts, self.device), 24 * 16
+
+    def _cyl_args(self, cyls: torch.Tensor, n: int):
+        if cyls.dim() == 1:
+            cyls = cyls[None]
+        if cyls.shape[0] == 1 or cyls.stride(0) == 0:
+            return _dev_f32(cyls[:1], self.device), 0
+        if cyls.shape[0] != n:
+            raise ValueError(f"cyls has {cyls.shape[0]} rows for {n} rays")
+        return _dev_f32(cyls, self.device), 5
+
+    def render_rays(self, ray_batch: torch.Tensor, skts: torch.Tensor, cyls: torch.Tensor,
+                    cams: Optional[torch.Tensor] = None, n_samples: Optional[int] = None,
+                    n_importance: Optional[int] = None, lindisp: bool = False,
+                    want_alpha: bool = True, extras: bool = False) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        S = cfg.n_samples if n_samples is None else int(n_samples)
+        N = cfg.n_importance if n_importance is None else int(n_importance)
+        rb = _dev_f32(ray_batch, self.device)
+        n = rb.shape[0]
+        if rb.dim() != 2 or rb.shape[1] < 8:
+            raise ValueError("ray_batch must be [n, >=8] (o, d, near, far [, viewdir])")
+        if rb.shape[1] != 11:
+            pad = torch.zeros(n, 11, device=self.device)
+            pad[:, :min(11, rb.shape[1])] = rb[:, :11]
+            rb = pad
+        sk, ps = self._pose_args(skts, n)
+        cy, cs = self._cyl_args(cyls, n)
+        cam = None
+        if cams is not None:
+            cam = _dev_f32(cams.reshape(-1), self.device)
+            if cam.shape[0] == 1 and n > 1:
+                cam = cam.expand(n).contiguous()
+        dev = self.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        SF = S + N
+        out = {"rgb_map": new(n, 3), "disp_map": new(n), "acc_map": new(n)}
+        if want_alpha:
+            out["alpha"] = new(n, SF)
+        if N > 0:
+            out.update({"rgb0": new(n, 3), "disp0": new(n), "acc0": new(n)})
+            if want_alpha:
+                out["alpha0"] = new(n, S)
+        ex = {}
+        if extras:
+            ex = {"near_far": new(n, 2), "z_coarse": new(n, S), "raw_coarse": new(n, S, 4), "weights0": new(n, S)}
+            if N > 0:
+                ex.update({"z_fine": new(n, SF), "raw_fine": new(n, SF, 4)})
+        po = _ffi.PgOutputs()
+        for k in ("rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"):
+            setattr(po, k, out[k].data_ptr() if k in out else None)
+        for k in ("near_far", "z_coarse", "z_fine", "raw_coarse", "raw_fine", "weights0"):
+            setattr(po, k, ex[k].data_ptr() if k in ex else None)
+        flags = _ffi.PG_FLAG_LINDISP if lindisp else 0
+        if n > 0:
+            self._check(self.lib.pg_render_rays(self.handle, self._stream(), n, _ptr(rb), _ptr(sk), ps, _ptr(cy), cs,
+                                                _ptr(cam), S, N, flags, C.byref(po)))
+        if extras:
+            out["extras"] = ex
+        return out
+
+    # -- stage entry points (tests / profiling) ---------------------------------------
+    def stage_sample_coarse(self, ray_batch, cyls, n_samples, lindisp=False):
+        rb = _dev_f32(ray_batch, self.device)
+        n = rb.shape[0]
+        cy, cs = self._cyl_args(cyls, n)
+        nf = torch.empty(n, 2, device=self.device)
+        z = torch.empty(n, n_samples, device=self.device)
+        self._check(self.lib.pg_stage_sample_coarse(self.handle, self._stream(), n, _ptr(rb), _ptr(cy), cs,
+                                                    int(n_samples), _ffi.PG_FLAG_LINDISP if lindisp else 0,
+                                                    _ptr(nf), _ptr(z)))
+        return nf, z
+
+    def stage_eval(self, which, ray_batch, z, skts, cams=None, want_dbg=False):
+        rb = _dev_f32(ray_batch, self.device)
+        zz = _dev_f32(z, self.device)
+        n, S = zz.shape
+        sk, ps = self._pose_args(skts, n)
+        cam = None if cams is None else _dev_f32(cams.reshape(-1), self.device)
+        raw = torch.empty(n, S, 4, device=self.device)
+        dbg = torch.zeros(n * S, 256, device=self.device) if want_dbg else None
+        self._check(self.lib.pg_stage_eval(self.handle, self._stream(), int(which), n, S, _ptr(rb), _ptr(zz),
+                                           _ptr(sk), ps, _ptr(cam), _ptr(raw), _ptr(dbg)))
+        return (raw, dbg) if want_dbg else raw
+
+    def stage_composite(self, ray_batch, z, raw, n_importance=0):
+        rb = _dev_f32(ray_batch, self.device)
+        zz = _dev_f32(z, self.device)
+        rw = _dev_f32(raw, self.device)
+        n, S = zz.shape
+        new = lambda *s: torch.empty(*s, device=self.device, dtype=torch.float32)
+        o = {"rgb_map": new(n, 3), "disp_map": new(n), "acc_map": new(n), "alpha": new(n, S),
+             "weights": new(n, S)}
+        zf = new(n, S + n_importance) if n_importance > 0 else None
+        self._check(self.lib.pg_stage_composite(self.handle, self._stream(), n, S, _ptr(rb), _ptr(zz), _ptr(rw),
+                                                _ptr(o["rgb_map"]), _ptr(o["disp_map"]), _ptr(o["acc_map"]),
+                                                _ptr(o["alpha"]), _ptr(o["weights"]), int(n_importance), _ptr(zf)))
+        if zf is not None:
+            o["z_fine"] = zf
+        return o
+
+
+class HipRayCaster:
+    """Call-compatible stand-in for `RayCaster` / `nn.DataParallel(RayCaster)`.
+
+    Reference call site: ``ray_caster(rays_flat[i:i+chunk].to('cuda'), **batch_kwargs)``
+    (core/trainer.py:74) with the kwargs of `render_kwargs_test`
+    (core/raycasters.py:156-178) plus the per-ray pose tensors.
+    """
+
+    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+        self.cfg = cfg
+        self.renderer = HipRenderer(cfg, device, precision)
+        self.training = False
+
+    # ---- construction helpers -------------------------------------------------------
+    @classmethod
+    def from_weights(cls, cfg, w_coarse, w_fine, tau_v, tau_d, device="cuda:0", precision=PREC_BF16):
+        rc = cls(cfg, device, precision)
+        rc.renderer.load_network(0, w_coarse)
+        if w_fine is not None:
+            rc.renderer.load_network(1, w_fine)
+        rc.renderer.set_embedder(0, tau_v)
+        rc.renderer.set_embedder(1, tau_d)
+        return rc
+
+    # ---- nn.Module-like surface the reference touches -------------------------------
+    @property
+    def module(self):            # trainer.py:267,272,506 reach through DataParallel
+        return self
+
+    def to(self, *a, **k):       # trainer.py:73 `ray_caster.to('cuda')`
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def parameters(self):
+        for sd in self.renderer._state.values():
+            for v in sd.values():
+                yield v
+
+    def state_dict(self):
+        sd = {k: dict(v) for k, v in self.renderer._state.items()}
+        sd.setdefault("embedbones_state_dict", {})
+        return sd
+
+    def load_state_dict(self, ckpt, strict=True):
+        r = self.renderer
+        if "network_fn_state_dict" in ckpt:
+            r.load_network(0, ckpt["network_fn_state_dict"])
+        elif strict:
+            raise KeyError("network_fn_state_dict")
+        if ckpt.get("network_fine_state_dict") is not None:
+            r.load_network(1, ckpt["network_fine_state_dict"])
+        for which, key in ((0, "embed_state_dict"), (1, "embeddirs_state_dict")):
+            e = ckpt.get(key)
+            if e is not None and "tau" in e:
+                r.set_embedder(which, float(e["tau"]), e.get("cutoff_dist"))
+            elif strict:
+                raise KeyError(key)
+
+    # ---- the call -------------------------------------------------------------------
+    def forward(self, ray_batch, N_samples=None, kp_batch=None, skts=None, cyls=None, bones=None,
+                cams=None, subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0,
+                network_fine=None, raw_noise_std=0., ray_noise_std=0., verbose=False, ext_scale=0.001,
+                pytest=False, preproc_kwargs=None, nerf_type="nerf", fwd_type="", use_viewdirs=True,
+                want_alpha=True, extras=False, **unused):
+        if fwd_type:
+            raise NotImplementedError(f"fwd_type={fwd_type!r} (density / mesh queries) is not on the HIP path")
+        if self.training or perturb or raw_noise_std or ray_noise_std:
+            raise NotImplementedError("HipRayCaster renders in eval mode only (perturb = noise = 0)")
+        if subject_idxs is not None:
+            raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
+        if skts is None or cyls is None:
+            raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
+        return self.renderer.render_rays(ray_batch, skts, cyls, cams=cams, n_samples=N_samples,
+                                         n_importance=N_importance, lindisp=bool(lindisp),
+                                         want_alpha=want_alpha, extras=extras)
+
+    __call__ = forward
+
+
+def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PREC_BF16):
+    """Counterpart of `create_raycaster` (core/raycasters.py:17-184) for rendering:
+    returns `render_kwargs_test` with the HIP caster under 'ray_caster'."""
+    caster = HipRayCaster(cfg, device, precision)
+    if ckpt is not None:
+        caster.load_state_dict(ckpt)
+    caster.eval()
+    return {"ray_caster": caster, "perturb": False, "N_importance": cfg.n_importance,
+            "N_samples": cfg.n_samples, "use_viewdirs": True, "raw_noise_std": 0., "ray_noise_std": 0.,
+            "ext_scale": cfg.ext_scale, "preproc_kwargs": {}, "lindisp": cfg.lindisp, "nerf_type": "nerf"}
