@@ -154,10 +154,14 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
 
 /* encode_inputs + run_network (raycasters.py:476-577, nerf.py:90-148) on n*S points
  * p = o + d*z: the fused embedding + MLP kernel.  raw [n,S,4] = (rgb_raw, sigma_raw).
- * dbg (optional) receives the fp32 pre-activation of density layer 0 [n*S,256]. */
+ * dbg (optional, [n*S,256] floats) receives one intermediate activation per point,
+ * selected by dbg_stage: 0 = pre-activation of density layer 0; 1..7 = output of density
+ * layer 1..7 (post-ReLU); 8 = feature_linear output; 9 = view layer output (128 used);
+ * 10 = view cutoff weights wd (24 used).  Stages > 0 are only honoured by the fp32-grade
+ * kernels (PG_PREC_FP32 / *X3). */
 int pg_stage_eval(pg_handle* h, void* stream, int which_net, int64_t n, int n_samples,
                   const float* ray_batch, const float* z, const float* skts,
-                  int64_t pose_stride, const float* cams, float* raw, float* dbg);
+                  int64_t pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage);
 
 /* raw2outputs (nerf.py:150-205) and, if n_importance > 0, isample_from_lineseg
  * (ray_utils.py:157-201, 255-289): wave-per-ray prefix-product compositing. */
@@ -165,6 +169,13 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
                        const float* ray_batch, const float* z, const float* raw,
                        float* rgb, float* disp, float* acc, float* alpha, float* weights,
                        int n_importance, float* z_fine /*[n,S+N] or NULL*/);
+
+/* Optional in-library timing of the fused embed+MLP kernel (the dominant kernel): while
+ * enabled, every launch is bracketed by hipEvents on the caller's stream.  pg_profile_read
+ * synchronises, returns the number of launches, their summed device time [ms] and the
+ * number of points they evaluated since the last read, and resets the counters. */
+int pg_profile_enable(pg_handle* h, int on);
+int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t* n_points);
 
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision. */

@@ -64,9 +64,11 @@ PROTOTYPES = {
     "pg_stage_sample_coarse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, C.c_int,
                                          C.c_int, _FP, _FP]),
     "pg_stage_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, _FP, _FP, _FP,
-                                C.c_int64, _FP, _FP, _FP]),
+                                C.c_int64, _FP, _FP, _FP, C.c_int]),
     "pg_stage_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP,
                                      _FP, _FP, C.c_int, _FP]),
+    "pg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pg_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 

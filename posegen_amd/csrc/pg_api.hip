@@ -4,9 +4,11 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/posegen_hip.h"
@@ -58,6 +60,10 @@ struct pg_handle {
     float* d_cut = nullptr;
     uint8_t* ws = nullptr;
     size_t ws_bytes = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+    int64_t prof_points = 0;
 };
 
 namespace {
@@ -81,6 +87,15 @@ int fail(pg_handle* h, int code, const char* fmt, ...) {
     } while (0)
 
 bool is_shape_a(int prec) { return prec == PG_PREC_BF16 || prec == PG_PREC_FP16; }
+
+// The split-operand modes are EXPERIMENTAL: on MI355X their kernels intermittently produce
+// wrong view-layer outputs for lanes 16..31 of some waves (DESIGN.md "Known issues").  They
+// stay compiled for investigation but must be enabled explicitly.
+bool x3_allowed() {
+    const char* e = std::getenv("POSEGEN_EXPERIMENTAL_X3");
+    return e && e[0] == '1';
+}
+bool is_x3(int prec) { return prec == PG_PREC_BF16X3 || prec == PG_PREC_FP16X3; }
 
 pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     pgpack::NetTensors t;
@@ -131,7 +146,7 @@ int check_ready(pg_handle* h, bool need_fine) {
 }
 
 int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
-                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg) {
+                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0) {
     const int prec = h->cfg.precision;
     int rc = ensure_stream(h, which, prec);
     if (rc) return rc;
@@ -152,6 +167,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.n_codes = ns.n_codes;
     a.tau_v = h->tau[0];
     a.tau_d = h->tau[1];
+    a.dbg_stage = dbg_stage;
     const bool sa = is_shape_a(prec);
     const int pts = sa ? pg_eval16_points_per_pass() : pg_eval32_points_per_pass();
     if (S < pts / (MAXR - 1))
@@ -159,8 +175,23 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const long long iters = (a.n_points + pts - 1) / pts;
     a.n_iters = (int)iters;
     const int grid = (int)(iters < h->n_cu ? iters : h->n_cu);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+        auto get = [&](hipEvent_t& ev) {
+            if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); return hipSuccess; }
+            return hipEventCreate(&ev);
+        };
+        PG_HIP(h, get(e0));
+        PG_HIP(h, get(e1));
+        PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
+    }
     int e = sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
+    if (h->profiling) {
+        PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
+        h->ev_used.emplace_back(e0, e1);
+        h->prof_points += a.n_points;
+    }
     if (e) return fail(h, PG_EHIP, "fused embed+MLP kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
@@ -184,6 +215,8 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
                     "pg_create: unsupported architecture (kernels are built for 24 joints, multires 7/4/0, "
                     "8x256 trunk, skip 4, view width 128, frame code 0|16)");
     if (cfg->precision < 0 || cfg->precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
+    if (is_x3(cfg->precision) && !x3_allowed())
+        return fail(nullptr, PG_EINVAL, "pg_create: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", cfg->precision);
     if (cfg->chunk <= 0) return fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
     if (!(cfg->density_scale > 0.f)) return fail(nullptr, PG_EINVAL, "pg_create: density_scale must be positive");
     pg_handle* h = new (std::nothrow) pg_handle();
@@ -218,6 +251,8 @@ void pg_destroy(pg_handle* h) {
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
     }
+    for (auto& pr : h->ev_used) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& ev : h->ev_free) (void)hipEventDestroy(ev);
     if (h->d_cut) (void)hipFree(h->d_cut);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -292,6 +327,8 @@ int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) 
 int pg_set_precision(pg_handle* h, int precision) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_set_precision: null handle");
     if (precision < 0 || precision >= PG_PREC_COUNT) return fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
+    if (is_x3(precision) && !x3_allowed())
+        return fail(h, PG_EINVAL, "pg_set_precision: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", precision);
     h->cfg.precision = precision;
     for (int w = 0; w < 2; ++w)
         if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision); if (rc) return rc; }
@@ -302,6 +339,32 @@ int pg_set_chunk(pg_handle* h, int chunk) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_set_chunk: null handle");
     if (chunk <= 0) return fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
     h->cfg.chunk = chunk;
+    return PG_OK;
+}
+
+int pg_profile_enable(pg_handle* h, int on) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_enable: null handle");
+    h->profiling = on != 0;
+    return PG_OK;
+}
+
+int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t* n_points) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_read: null handle");
+    PG_HIP(h, hipSetDevice(h->device));
+    double ms = 0.0;
+    for (auto& pr : h->ev_used) {
+        PG_HIP(h, hipEventSynchronize(pr.second));
+        float t = 0.f;
+        PG_HIP(h, hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        h->ev_free.push_back(pr.first);
+        h->ev_free.push_back(pr.second);
+    }
+    if (n_launches) *n_launches = (int64_t)h->ev_used.size();
+    if (total_ms) *total_ms = ms;
+    if (n_points) *n_points = h->prof_points;
+    h->ev_used.clear();
+    h->prof_points = 0;
     return PG_OK;
 }
 
@@ -332,7 +395,8 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
 }
 
 int pg_stage_eval(pg_handle* h, void* stream, int which, int64_t n, int n_samples, const float* ray_batch,
-                  const float* z, const float* skts, int64_t pose_stride, const float* cams, float* raw, float* dbg) {
+                  const float* z, const float* skts, int64_t pose_stride, const float* cams, float* raw, float* dbg,
+                  int dbg_stage) {
     int rc = check_ready(h, which == 1);
     if (rc) return rc;
     if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_stage_eval: which_net must be 0 or 1");
@@ -340,7 +404,7 @@ int pg_stage_eval(pg_handle* h, void* stream, int which, int64_t n, int n_sample
     if (pose_stride != 0 && pose_stride != 384) return fail(h, PG_EINVAL, "pose_stride must be 0 or 384");
     if (n == 0) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
-    return launch_eval(h, stream, which, n, n_samples, ray_batch, z, skts, pose_stride, cams, raw, dbg);
+    return launch_eval(h, stream, which, n, n_samples, ray_batch, z, skts, pose_stride, cams, raw, dbg, dbg_stage);
 }
 
 int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, const float* ray_batch, const float* z,

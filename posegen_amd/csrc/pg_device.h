@@ -30,6 +30,7 @@ struct EvalArgs {
     int n_codes;
     int n_iters;              // workgroup passes = ceil(n_points / points per pass)
     float tau_v, tau_d;
+    int dbg_stage;            // which activation `dbg` receives (see pg_stage_eval)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -46,10 +47,15 @@ struct Stream {
     const uint8_t* wstream;
     uint8_t* ring;
     int wave, lane;
-    // Byte offset of the NEXT chunk to fetch.  Kept as loop-carried state on purpose:
-    // computed from the chunk index it would be a loop invariant per chunk, and hipcc
-    // hoists all NCHUNK 64-bit source addresses to kernel entry and spills them.
+    // Byte offset of the NEXT chunk to fetch.  Kept as loop-carried, optimizer-opaque
+    // state on purpose: computed from the chunk index it is a loop invariant per chunk,
+    // and hipcc hoists all NCHUNK 64-bit source addresses to kernel entry and spills them.
     uint32_t next_off;
+    // This lane's read offset into the ring (lane*16), re-defined by an empty asm at
+    // every enter().  hipcc does not model global_load_lds as a write to LDS: without
+    // this data dependence it CSEs / hoists ds_reads of a ring address across barriers
+    // and DMA fills and feeds MFMAs a previous chunk's bytes (seen on the split kernels).
+    uint32_t rd_off;
     static constexpr int PER = 16 / NWAVE;
 
     __device__ __forceinline__ void prefetch_next(int slot) {
@@ -58,18 +64,24 @@ struct Stream {
 #pragma unroll
         for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
         next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
-        asm volatile("" : "+s"(next_off));      // opaque: stops constant folding + hoisting
+        asm volatile("" : "+s"(next_off));
     }
     // kernel start: fetch chunk 0 into slot 0
-    __device__ __forceinline__ void start() { next_off = 0; prefetch_next(0); }
-    // entering chunk c (chunks are entered strictly in order 0..NCHUNK-1, 0, ...)
+    __device__ __forceinline__ void start() {
+        next_off = 0;
+        rd_off = lane * 16;
+        prefetch_next(0);
+    }
+    // entering chunk c (chunks are entered strictly in order 0..NCHUNK-1, 0, ...):
+    // own DMA pieces landed -> workgroup barrier -> chunk c readable, other slot free
     __device__ __forceinline__ void enter(int c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         prefetch_next((c + 1) & 1);
+        asm volatile("" : "+v"(rd_off) :: "memory");
     }
     __device__ __forceinline__ const uint8_t* at(int c, int byte_off) const {
-        return ring + (c & 1) * CHUNK_BYTES + byte_off + lane * 16;
+        return ring + (c & 1) * CHUNK_BYTES + byte_off + rd_off;
     }
 };
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u};
+    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
 #pragma unroll
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
             x_segment<V>(acc, st, C_L0, slot, cut, a.tau_v, px, py, pz, h);
-            if (a.dbg && valid) {
+            if (a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
 #pragma unroll

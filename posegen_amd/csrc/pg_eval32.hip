@@ -27,6 +27,7 @@ struct PolF32 {
     static constexpr int UPC = CHUNK_BYTES / UBYTES;
     struct B { float v[4]; };
     static __device__ __forceinline__ B prep(const float* x) { return B{{x[0], x[1], x[2], x[3]}}; }
+    static __device__ __forceinline__ float roundtrip(float x) { return x; }
     static __device__ __forceinline__ f32x16 mma(const uint8_t* u, const B& b, f32x16 acc) {
         const float4 a = *reinterpret_cast<const float4*>(u);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.v[0], acc, 0, 0, 0);
@@ -57,6 +58,10 @@ struct PolX3 {
     static constexpr int UBYTES = 2048;          // hi plane then lo plane
     static constexpr int UPC = CHUNK_BYTES / UBYTES;
     struct B { V hi, lo; };
+    static __device__ __forceinline__ float roundtrip(float x) {
+        const typename Split<V>::E hi = (typename Split<V>::E)x;
+        return (float)hi + (float)(typename Split<V>::E)(x - (float)hi);
+    }
     static __device__ __forceinline__ B prep(const float* x) {
         B b;
 #pragma unroll
@@ -129,6 +134,15 @@ __device__ __forceinline__ void store_act(const f32x16* acc, float* act, bool re
         for (int r = 0; r < 16; ++r) act[16 * o + r] = relu ? fmaxf(acc[o][r], 0.0f) : acc[o][r];
 }
 
+// debug: activation values of this lane (sequence order, see hseq_channel) -> dbg[pt][256]
+template <int NVAL>
+__device__ __forceinline__ void dump_act(const EvalArgs& a, int stage, long long gp, bool valid, const float* act, int h) {
+    if (a.dbg && a.dbg_stage == stage && valid) {
+#pragma unroll
+        for (int i = 0; i < NVAL; ++i) a.dbg[gp * W + hseq_channel(i, h)] = act[i];
+    }
+}
+
 template <typename P, bool FC>
 __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u};
+    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR_B) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
 #pragma unroll
         for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
         x_segment<P>(acc, st, C_L0, slot, cut, a.tau_v, px, py, pz, h);
-        if (a.dbg && valid) {
+        if (a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
             for (int o = 0; o < NT; ++o)
 #pragma unroll
@@ -183,6 +197,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + l * NT + o, h);
             hidden_segment<P, NT>(acc, st, C_L1 + (l - 1) * CH_HID, act, HSEQ);
             store_act<NT>(acc, act, true);
+            dump_act<HSEQ>(a, l, gp, valid, act, h);
         }
         // ---- layer 5 (skip) ----
 #pragma unroll
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         hidden_segment<P, NT>(acc, st, C_L5H, act, HSEQ);
         x_segment<P>(acc, st, C_L5X, slot, cut, a.tau_v, px, py, pz, h);
         store_act<NT>(acc, act, true);
+        dump_act<HSEQ>(a, 5, gp, valid, act, h);
         // ---- layers 6, 7 ----
 #pragma unroll
         for (int l = 6; l <= 7; ++l) {
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + l * NT + o, h);
             hidden_segment<P, NT>(acc, st, C_L6 + (l - 6) * CH_HID, act, HSEQ);
             store_act<NT>(acc, act, true);
+            dump_act<HSEQ>(a, l, gp, valid, act, h);
         }
         // ---- feature (no activation) and sigma heads, both on h7 ----
 #pragma unroll
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         hidden_segment<P, 1>(&acc1, st, C_ALPHA, act, HSEQ);
         const float sigma = acc1[0];
         store_act<NT>(acc, act, false);
+        dump_act<HSEQ>(a, 8, gp, valid, act, h);
         // ---- view layer ----
         f32x16 accv[NTV];
 #pragma unroll
@@ -217,6 +235,10 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             for (int jj = 0; jj < JH; ++jj)
                 wd[jj] = cutoff_weight(joint_dist(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
                                        a.tau_d, cut[J + JH * h + jj]);
+            if (a.dbg && a.dbg_stage == 10 && valid) {
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) a.dbg[gp * W + JH * h + jj] = wd[jj];
+            }
             const float* tab = slot + SLOT_DTAB + h * DSEQ;
 #pragma unroll
             for (int uu = 0; uu < DSEQ / 8; ++uu) {
@@ -228,6 +250,10 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
                     const int k = uu < JH * 3 ? uu / 3 : (8 * (uu - JH * 3) + e) / 3;
                     x[e] = k < JH ? x[e] * wd[k] : 0.0f;
                 }
+                if (a.dbg && a.dbg_stage == 11 && valid && uu < 16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a.dbg[gp * W + h * 128 + uu * 8 + e] = P::roundtrip(x[e]);
+                }
                 feed<P, NTV>(accv, st, C_VD, uu * 8, x, 8);
             }
             if (FC) {
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             }
         }
         store_act<NTV>(accv, act, true);
+        dump_act<VW / 2>(a, 9, gp, valid, act, h);
         // ---- rgb head ----
         f32x16 accr = load_bias(bias, BT_RGB, h);
         hidden_segment<P, 1>(&accr, st, C_RGB, act, VW / 2);

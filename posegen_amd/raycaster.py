@@ -119,6 +119,15 @@ class HipRenderer:
             self._check(self.lib.pg_set_chunk(self.handle, int(chunk)))
             self._chunk = int(chunk)
 
+    def profile_enable(self, on=True):
+        self._check(self.lib.pg_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        """(launches, summed device ms, points) of the fused embed+MLP kernel since the last read."""
+        n, ms, pts = C.c_int64(), C.c_double(), C.c_int64()
+        self._check(self.lib.pg_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(pts)))
+        return n.value, ms.value, pts.value
+
     def query(self, precision=None):
         sb, mf = C.c_int64(), C.c_int64()
         self._check(self.lib.pg_query(self.handle, self.precision if precision is None else int(precision),
@@ -207,7 +216,7 @@ class HipRenderer:
                                                     _ptr(nf), _ptr(z)))
         return nf, z
 
-    def stage_eval(self, which, ray_batch, z, skts, cams=None, want_dbg=False):
+    def stage_eval(self, which, ray_batch, z, skts, cams=None, want_dbg=False, dbg_stage=0):
         rb = _dev_f32(ray_batch, self.device)
         zz = _dev_f32(z, self.device)
         n, S = zz.shape
@@ -216,7 +225,7 @@ class HipRenderer:
         raw = torch.empty(n, S, 4, device=self.device)
         dbg = torch.zeros(n * S, 256, device=self.device) if want_dbg else None
         self._check(self.lib.pg_stage_eval(self.handle, self._stream(), int(which), n, S, _ptr(rb), _ptr(zz),
-                                           _ptr(sk), ps, _ptr(cam), _ptr(raw), _ptr(dbg)))
+                                           _ptr(sk), ps, _ptr(cam), _ptr(raw), _ptr(dbg), int(dbg_stage)))
         return (raw, dbg) if want_dbg else raw
 
     def stage_composite(self, ray_batch, z, raw, n_importance=0):
