@@ -177,6 +177,14 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
 int pg_profile_enable(pg_handle* h, int on);
 int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t* n_points);
 
+/* Host-only (no GPU touched): pack one net's tensors (same 24-tensor order as
+ * pg_load_weights) into the weight stream and bias table the kernels consume, for tests
+ * of the packing / stream-program logic.  stream_out may be NULL to query the size. */
+int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors,
+                  int framecode_ch, int precision, uint8_t* stream_out, int64_t stream_cap,
+                  int64_t* stream_bytes, float* bias_out /* 78*32 floats or NULL */,
+                  int32_t* chunk_bytes /* out: ring chunk size the library was built with */);
+
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision. */
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group);

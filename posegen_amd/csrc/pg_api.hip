@@ -368,6 +368,33 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
     return PG_OK;
 }
 
+int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
+                  int precision, uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes, float* bias_out,
+                  int32_t* chunk_bytes) {
+    if (!tensors || !shapes || n_tensors != 24) return fail(nullptr, PG_EINVAL, "pg_debug_pack: need 24 tensors");
+    if (precision < 0 || precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_debug_pack: bad precision");
+    NetState ns;
+    ns.host.assign(24, {});
+    for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + shapes[2 * i] * shapes[2 * i + 1]);
+    pg_config cfg{};
+    cfg.framecode_ch = framecode_ch;
+    std::vector<uint8_t> packed;
+    const int rc = pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, packed);
+    if (rc != 0) return fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
+    if (stream_bytes) *stream_bytes = (int64_t)packed.size();
+    if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
+    if (stream_out) {
+        if ((int64_t)packed.size() > stream_cap) return fail(nullptr, PG_EINVAL, "pg_debug_pack: buffer too small");
+        std::memcpy(stream_out, packed.data(), packed.size());
+    }
+    if (bias_out) {
+        std::vector<float> bias;
+        pgpack::pack_bias(tensors_of(ns, cfg), bias);
+        std::memcpy(bias_out, bias.data(), bias.size() * sizeof(float));
+    }
+    return PG_OK;
+}
+
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_query: null handle");
     if (precision < 0 || precision >= PG_PREC_COUNT) return PG_EINVAL;

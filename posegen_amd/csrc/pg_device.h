@@ -38,51 +38,64 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// Weight-stream consumer state of one wave: a 2-slot LDS ring of 16-KiB chunks filled by
-// LDS-DMA.  Every wave copies 16/NWAVE of the chunk's 1-KiB pieces; `enter(c)` is the
-// only synchronisation: own pieces landed (vmcnt 0) -> workgroup barrier -> chunk c is
-// readable by everyone, the other slot (chunk c-1) is free -> start chunk c+1 into it.
+// Weight-stream consumer state of one wave: an NSLOT-deep LDS ring of 16-KiB chunks filled
+// by LDS-DMA (global_load_lds_dwordx4), DEPTH = NSLOT-1 chunks in flight.  Every wave copies
+// 16/NWAVE of each chunk's 1-KiB pieces.  `enter()` is the only synchronisation:
+//   counted vmcnt (own pieces of the chunk being entered have landed; the younger chunks'
+//   DMA stays in flight across the barrier) -> lgkmcnt(0) (own reads of the previous chunk
+//   returned) -> raw s_barrier -> the chunk is readable by every wave and the slot of the
+//   previous chunk is free -> start the DMA of chunk +DEPTH into it.
+// Chunks are consumed strictly in stream order, wrapping from NCHUNK-1 to 0.
+#ifndef PG_RING_SLOTS
+#define PG_RING_SLOTS 3
+#endif
 template <int NWAVE, int NCHUNK_>
 struct Stream {
+    static constexpr int NSLOT = PG_RING_SLOTS;
+    static constexpr int DEPTH = NSLOT - 1;
+    static constexpr int PER = CHUNK_BYTES / 1024 / NWAVE;   // DMA instructions per wave per chunk
     const uint8_t* wstream;
     uint8_t* ring;
     int wave, lane;
-    // Byte offset of the NEXT chunk to fetch.  Kept as loop-carried, optimizer-opaque
-    // state on purpose: computed from the chunk index it is a loop invariant per chunk,
-    // and hipcc hoists all NCHUNK 64-bit source addresses to kernel entry and spills them.
-    uint32_t next_off;
-    // This lane's read offset into the ring (lane*16), re-defined by an empty asm at
-    // every enter().  hipcc does not model global_load_lds as a write to LDS: without
-    // this data dependence it CSEs / hoists ds_reads of a ring address across barriers
-    // and DMA fills and feeds MFMAs a previous chunk's bytes (seen on the split kernels).
-    uint32_t rd_off;
-    static constexpr int PER = 16 / NWAVE;
+    // Loop-carried, optimizer-opaque state (asm "+s"/"+v" below).  Derived from the chunk
+    // index these would be per-chunk loop invariants, and hipcc (a) hoists every chunk's
+    // 64-bit source address to kernel entry and spills them, (b) does not model
+    // global_load_lds as a write to LDS, so it may CSE/hoist ring reads across fills.
+    uint32_t next_off;     // byte offset in the stream of the next chunk to fetch
+    uint32_t fill_slot;    // ring slot that fetch goes to
+    uint32_t rd_off;       // this lane's byte offset into the ring for the current chunk
 
-    __device__ __forceinline__ void prefetch_next(int slot) {
+    __device__ __forceinline__ void prefetch_next() {
         const uint8_t* src = wstream + next_off + (wave * (PER * 1024) + lane * 16);
-        uint8_t* dst = ring + slot * CHUNK_BYTES + wave * (PER * 1024);
+        uint8_t* dst = ring + fill_slot * CHUNK_BYTES + wave * (PER * 1024);
 #pragma unroll
         for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
         next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
-        asm volatile("" : "+s"(next_off));
+        fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
+        asm volatile("" : "+s"(next_off), "+s"(fill_slot));
     }
-    // kernel start: fetch chunk 0 into slot 0
+    // kernel start: DEPTH chunks in flight; the first enter() consumes slot 0
     __device__ __forceinline__ void start() {
         next_off = 0;
-        rd_off = lane * 16;
-        prefetch_next(0);
+        fill_slot = 0;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) prefetch_next();
+        rd_off = (uint32_t)(NSLOT - 1) * CHUNK_BYTES + lane * 16;   // advanced by the first enter()
     }
-    // entering chunk c (chunks are entered strictly in order 0..NCHUNK-1, 0, ...):
-    // own DMA pieces landed -> workgroup barrier -> chunk c readable, other slot free
-    __device__ __forceinline__ void enter(int c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        prefetch_next((c + 1) & 1);
-        asm volatile("" : "+v"(rd_off) :: "memory");
+    __device__ __forceinline__ void enter(int /*chunk index, documentation only*/) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        prefetch_next();
+        rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES
+                                                                                  : rd_off + CHUNK_BYTES;
+        asm volatile("" : "+v"(rd_off)::"memory");
     }
-    __device__ __forceinline__ const uint8_t* at(int c, int byte_off) const {
-        return ring + (c & 1) * CHUNK_BYTES + byte_off + rd_off;
+    __device__ __forceinline__ const uint8_t* at(int /*chunk*/, int byte_off) const {
+        return ring + byte_off + rd_off;
     }
+    // before the wave exits: no DMA may be left in flight
+    __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 __device__ __forceinline__ f32x16 load_bias(const float* bias, int tile, int h) {
@@ -93,12 +106,13 @@ __device__ __forceinline__ f32x16 load_bias(const float* bias, int tile, int h) 
 }
 
 // LDS carve-up (bytes) shared by both kernel shapes
-constexpr int LDS_RING = 0;                                  // 2 x CHUNK_BYTES
-constexpr int LDS_BIAS = 2 * CHUNK_BYTES;                    // BIAS_FLOATS floats
+constexpr int LDS_RING = 0;                                  // PG_RING_SLOTS x CHUNK_BYTES
+constexpr int LDS_BIAS = PG_RING_SLOTS * CHUNK_BYTES;        // BIAS_FLOATS floats
 constexpr int LDS_CUT = LDS_BIAS + BIAS_FLOATS * 4;          // 48 floats
 constexpr int LDS_RTAB = LDS_CUT + 48 * 4;                   // MAXR slots
 constexpr int LDS_TOTAL = LDS_RTAB + MAXR * SLOT_FLOATS * 4;
 static_assert(LDS_BIAS % 16 == 0 && LDS_CUT % 16 == 0 && LDS_RTAB % 16 == 0, "LDS alignment");
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 
 // q = (skt @ [p;1]).xyz with skt rows 0..2 at sk[0..11]      (core/encoders.py:8-23)
 __device__ __forceinline__ void bone_local(const float* sk, float px, float py, float pz,
@@ -111,24 +125,44 @@ __device__ __forceinline__ void bone_local(const float* sk, float px, float py, 
     qz = fmaf(c.z, pz, fmaf(c.y, py, fmaf(c.x, px, c.w)));
 }
 
-// cutoff weight 1 - sigmoid(tau (v - c))                     (cutoff_embedder.py:139-146)
+// Math flavour of the per-point embedding.  ACCURATE: correctly-rounded sqrt / division and
+// ocml expf / sincosf (fp32-grade kernels, parity mode).  FAST: the hardware transcendental
+// units (v_sqrt / v_rcp / v_exp / v_sin / v_cos, ~1e-6 relative) -- used by the 16-bit
+// operand kernels, whose operands are rounded to 8-11 bits right afterwards.
+template <bool FAST> __device__ __forceinline__ float pg_sqrt(float x) {
+    return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x);
+}
+template <bool FAST> __device__ __forceinline__ float pg_div(float a, float b) {
+    return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b;
+}
+
+// cutoff weight 1 - sigmoid(tau (v - c)) = 1 / (1 + exp(t))       (cutoff_embedder.py:139-146)
+template <bool FAST>
 __device__ __forceinline__ float cutoff_weight(float v, float tau, float c) {
     const float t = tau * (v - c);
+    if (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * 1.4426950408889634f));
     return 1.0f - 1.0f / (1.0f + expf(-t));
 }
 
 // The 18 density-input values of one joint for one point (RelDist + VecNorm + cutoff
 // embedding, encoders.py:101-122,172-193; cutoff_embedder.py:111-174):
 //   x[0] = v w, x[1+2f] = sin(2^f v) w, x[2+2f] = cos(2^f v) w (f < 7), x[15..17] = q/|q|
-// sin/cos of the octaves by exact angle doubling from one accurate sincosf.
+// sin/cos of the octaves by exact angle doubling from one sincos of v.
+template <bool FAST>
 __device__ __forceinline__ void joint_values(const float* sk, float px, float py, float pz,
                                              float tau, float cut, float* x) {
     float qx, qy, qz;
     bone_local(sk, px, py, pz, qx, qy, qz);
-    const float v = sqrtf(qx * qx + qy * qy + qz * qz);
-    const float w = cutoff_weight(v, tau, cut);
+    const float v = pg_sqrt<FAST>(qx * qx + qy * qy + qz * qz);
+    const float w = cutoff_weight<FAST>(v, tau, cut);
     float s, c;
-    sincosf(v, &s, &c);
+    if (FAST) {
+        const float rev = v * 0.15915494309189535f;      // v_sin/v_cos take revolutions
+        s = __builtin_amdgcn_sinf(rev);
+        c = __builtin_amdgcn_cosf(rev);
+    } else {
+        sincosf(v, &s, &c);
+    }
     x[0] = v * w;
 #pragma unroll
     for (int f = 0; f < LV; ++f) {
@@ -138,17 +172,21 @@ __device__ __forceinline__ void joint_values(const float* sk, float px, float py
         c = (c - s) * (c + s);
         s = s2;
     }
-    const float den = fmaxf(v, 1e-12f);
-    x[15] = qx / den;
-    x[16] = qy / den;
-    x[17] = qz / den;
+    const float inv = pg_div<FAST>(1.0f, fmaxf(v, 1e-12f));
+    if (FAST) {
+        x[15] = qx * inv; x[16] = qy * inv; x[17] = qz * inv;
+    } else {
+        const float den = fmaxf(v, 1e-12f);
+        x[15] = qx / den; x[16] = qy / den; x[17] = qz / den;
+    }
 }
 
 // distance of the point to one joint (for the view-embedding cutoff weight)
+template <bool FAST>
 __device__ __forceinline__ float joint_dist(const float* sk, float px, float py, float pz) {
     float qx, qy, qz;
     bone_local(sk, px, py, pz, qx, qy, qz);
-    return sqrtf(qx * qx + qy * qy + qz * qz);
+    return pg_sqrt<FAST>(qx * qx + qy * qy + qz * qz);
 }
 
 // Fill the per-ray LDS table for the rays [r0, r0+nr) this pass touches.

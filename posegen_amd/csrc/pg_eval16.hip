@@ -75,7 +75,7 @@ __device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, 
         for (int k = 0; k < 4; ++k) {
             const int jj = 4 * sb + k;
             float x[18];
-            joint_values(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
+            joint_values<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
             lo[2 * k] = x[16];
             lo[2 * k + 1] = x[17];
             mma_row<V, NT>(acc, st, cbase, sb * 9 + 2 * k, Op<V>::cvt(x));
@@ -85,26 +85,64 @@ __device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, 
     }
 }
 
+// ReLU on packed 16-bit floats: a negative bf16/fp16 is a negative int16, so max_i16(x, 0)
+// clears exactly the negative lanes (v_pk_max_i16: one VALU op per two channels; fmaxf on the
+// fp32 accumulators costs two each because hipcc canonicalises MFMA results first).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// One asm statement per fragment; the trailing s_nop 1 provides the two wait states a VALU
+// write needs before an MFMA may read the register (hipcc pads nothing for inline asm).
+template <typename V>
+__device__ __forceinline__ V relu16(V v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+    unsigned r0, r1, r2, r3;
+    asm("v_pk_max_i16 %0, %4, 0\n\tv_pk_max_i16 %1, %5, 0\n\tv_pk_max_i16 %2, %6, 0\n\tv_pk_max_i16 %3, %7, 0\n\ts_nop 1"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)      // early-clobber: outputs are written
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));      // before the later inputs are read
+    const u32x4 o = {r0, r1, r2, r3};
+    return __builtin_bit_cast(V, o);
+}
+
 template <typename V>
 __device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool relu) {
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+    for (int r = 0; r < 16; ++r) t[r] = acc[r];
     f0 = Op<V>::cvt(t);
     f1 = Op<V>::cvt(t + 8);
+    if (relu) { f0 = relu16<V>(f0); f1 = relu16<V>(f1); }
 }
 
-// fout = relu(W fin + b), out-tile-major segment of NT chunks starting at cbase
+// acc += W[tile o] * fin over the HU hidden units; out-tile-major segment starting at cbase
+template <typename V>
+__device__ __forceinline__ void row_tile(f32x16& acc, Stream16& st, int cbase, int o, const V* fin) {
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+        const int L = o * HU + u;
+        if (L % UPC == 0) st.enter(cbase + L / UPC);
+        acc = Op<V>::mfma(unit_of<V>(st, cbase + L / UPC, L % UPC), fin[u], acc);
+    }
+}
+
+// fout = relu(W fin + b), out-tile-major segment starting at chunk cbase
 template <typename V>
 __device__ __forceinline__ void hidden_layer(const V* fin, V* fout, Stream16& st, int cbase,
                                              const float* bias, int tile0, int h) {
 #pragma unroll
     for (int o = 0; o < NT; ++o) {
-        st.enter(cbase + o);
         f32x16 acc = load_bias(bias, tile0 + o, h);
-#pragma unroll
-        for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(unit_of<V>(st, cbase + o, u), fin[u], acc);
+        row_tile<V>(acc, st, cbase, o, fin);
         relu_pack<V>(acc, fout[2 * o], fout[2 * o + 1], true);
+    }
+}
+
+// debug: write a fragment array (H-sequence order) as floats to dbg[pt][256]
+template <typename V, int NF>
+__device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long long gp, bool valid, const V* f, int h) {
+    if (a.dbg && a.dbg_stage == stage && valid) {
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a.dbg[gp * W + hseq_channel(8 * u + j, h)] = (float)f[u][j];
     }
 }
 
@@ -116,7 +154,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u};
+    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
@@ -167,10 +205,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             f32x16 acc[NT];
 #pragma unroll
             for (int o = 0; o < NT; ++o) {
-                st.enter(C_L5H + o);
                 acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
-#pragma unroll
-                for (int u = 0; u < HU; ++u) acc[o] = Op<V>::mfma(unit_of<V>(st, C_L5H + o, u), fa[u], acc[o]);
+                row_tile<V>(acc[o], st, C_L5H, o, fa);
             }
             x_segment<V>(acc, st, C_L5X, slot, cut, a.tau_v, px, py, pz, h);
 #pragma unroll
@@ -182,28 +218,26 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         float sigma;
 #pragma unroll
         for (int o = 0; o < NT + 1; ++o) {
-            st.enter(C_FA + o);
             f32x16 acc = load_bias(bias, BT_FEAT + o, h);      // tile 8 = BT_ALPHA
-#pragma unroll
-            for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(unit_of<V>(st, C_FA + o, u), fb[u], acc);
+            row_tile<V>(acc, st, C_FA, o, fb);
             if (o < NT) relu_pack<V>(acc, fa[2 * o], fa[2 * o + 1], false);
             else sigma = acc[0];
         }
+        dump_frags<V, HU>(a, 7, gp, valid, fb, h);
+        dump_frags<V, HU>(a, 8, gp, valid, fa, h);
         // ---- view layer: [feature(256), xd(648) (, code16)] -> 128, relu ----
         V fg[HU / 2];
         {
             f32x16 acc[NTV];
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
-                st.enter(C_VF + o);
                 acc[o] = load_bias(bias, BT_VIEW + o, h);
-#pragma unroll
-                for (int u = 0; u < HU; ++u) acc[o] = Op<V>::mfma(unit_of<V>(st, C_VF + o, u), fa[u], acc[o]);
+                row_tile<V>(acc[o], st, C_VF, o, fa);
             }
             float wd[JH];
 #pragma unroll
             for (int jj = 0; jj < JH; ++jj)
-                wd[jj] = cutoff_weight(joint_dist(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
+                wd[jj] = cutoff_weight<true>(joint_dist<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
                                        a.tau_d, cut[J + JH * h + jj]);
             const float* tab = slot + SLOT_DTAB + h * DSEQ;
 #pragma unroll
@@ -227,18 +261,16 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
 #pragma unroll
             for (int o = 0; o < NTV; ++o) relu_pack<V>(acc[o], fg[2 * o], fg[2 * o + 1], true);
         }
+        dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
         // ---- rgb head ----
         st.enter(C_RGB);
         f32x16 acc = load_bias(bias, BT_RGB, h);
 #pragma unroll
         for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(unit_of<V>(st, C_RGB, u), fg[u], acc);
-        // chunk C_RGB+1 (= NCHUNK-1) is padding: step through it so that chunk 0 of the
-        // next pass is prefetched into ring slot 0 with the usual protocol
-        st.enter(C_RGB + 1);
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(acc[0], acc[1], acc[2], sigma);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st.drain();
 }
 
 template <typename V, bool FC>

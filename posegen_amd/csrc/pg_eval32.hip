@@ -111,7 +111,7 @@ __device__ __forceinline__ void x_segment(f32x16* acc, Stream32& st, int cbase, 
         for (int k = 0; k < 4; ++k) {
             const int jj = 4 * sb + k;
             float x[18];
-            joint_values(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
+            joint_values<false>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
             lo[2 * k] = x[16];
             lo[2 * k + 1] = x[17];
             feed<P, NT>(acc, st, cbase, sb * 72 + k * 16, x, 16);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u};
+    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR_B) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             float wd[JH];
 #pragma unroll
             for (int jj = 0; jj < JH; ++jj)
-                wd[jj] = cutoff_weight(joint_dist(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
+                wd[jj] = cutoff_weight<false>(joint_dist<false>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
                                        a.tau_d, cut[J + JH * h + jj]);
             if (a.dbg && a.dbg_stage == 10 && valid) {
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st.drain();
 }
 
 template <typename P, bool FC>

@@ -47,7 +47,10 @@ constexpr int DEPTH = 8;
 constexpr int SKIP = 4;          // concat after layer 4 -> layer 5 has K = 432+256
 constexpr int FC_CH = 16;        // frame code channels (when enabled)
 
-constexpr int CHUNK_BYTES = 16384;   // LDS ring slot = 16 units of 1 KiB
+#ifndef PG_CHUNK_KB
+#define PG_CHUNK_KB 32
+#endif
+constexpr int CHUNK_BYTES = PG_CHUNK_KB * 1024;   // LDS ring slot (16 or 32 units of 1 KiB)
 constexpr int UNIT_BYTES = 1024;
 
 // lane-value sequences ------------------------------------------------------------

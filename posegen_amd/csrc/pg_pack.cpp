@@ -144,8 +144,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, std::vector<uint8_t
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
     const size_t nchunk = shape == SHAPE_A ? A::NCHUNK : B::NCHUNK;
-    if (out.size() > nchunk * CHUNK_BYTES) return -2;
-    out.resize(nchunk * CHUNK_BYTES, 0);
+    if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
 }
 

@@ -22,24 +22,26 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---------------- shape A: 16-bit operands, 8 values per lane per unit -------------
 namespace A {
 constexpr int UE = 8;                         // values per lane per unit
-constexpr int UPC = 16;                       // units per chunk
+constexpr int UPC = CHUNK_BYTES / UNIT_BYTES; // units per chunk
 constexpr int XU = XSEQ / UE;                 // 27
 constexpr int HU = HSEQ / UE;                 // 16
 constexpr int DU = DSEQ / UE;                 // 41
-constexpr int CH_L0X = cdiv(XU * NT, UPC);    // 14
-constexpr int CH_HID = HU * NT / UPC;         // 8
+constexpr int CH_L0X = cdiv(XU * NT, UPC);
+constexpr int CH_HID = cdiv(HU * NT, UPC);
 constexpr int C_L0 = 0;
-constexpr int C_L1 = C_L0 + CH_L0X;           // 14  (L1..L4 consecutive)
-constexpr int C_L5H = C_L1 + 4 * CH_HID;      // 46
-constexpr int C_L5X = C_L5H + CH_HID;         // 54
-constexpr int C_L6 = C_L5X + CH_L0X;          // 68  (L6, L7 consecutive)
-constexpr int C_FA = C_L6 + 2 * CH_HID;       // 84
-constexpr int C_VF = C_FA + 9;                // 93
-constexpr int C_VD = C_VF + NTV;              // 97
-constexpr int CH_VD = 11;                     // cdiv((41 [+1]) * 4, 16)
-constexpr int C_RGB = C_VD + CH_VD;           // 108
-constexpr int NCHUNK = 110;                   // 109 rounded up to even (static ring parity)
-static_assert(cdiv((DU + 1) * NTV, UPC) == CH_VD && cdiv(DU * NTV, UPC) == CH_VD, "view chunks");
+constexpr int C_L1 = C_L0 + CH_L0X;           // L1..L4 consecutive
+constexpr int C_L5H = C_L1 + 4 * CH_HID;
+constexpr int C_L5X = C_L5H + CH_HID;
+constexpr int C_L6 = C_L5X + CH_L0X;          // L6, L7 consecutive
+constexpr int C_FA = C_L6 + 2 * CH_HID;
+constexpr int CH_FA = cdiv(HU * (NT + 1), UPC);
+constexpr int C_VF = C_FA + CH_FA;
+constexpr int CH_VF = cdiv(HU * NTV, UPC);
+constexpr int C_VD = C_VF + CH_VF;
+constexpr int CH_VD = cdiv((DU + 1) * NTV, UPC);
+constexpr int C_RGB = C_VD + CH_VD;
+constexpr int NCHUNK = C_RGB + 1;
+static_assert(cdiv(DU * NTV, UPC) == CH_VD, "view segment must take the same chunks with and without frame code");
 // MFMAs issued per 32-point group (for pg_query / roofline bookkeeping)
 constexpr int MFMA_PER_GROUP(bool fc) {
     return XU * NT * 2 + 6 * HU * NT + HU * NT /*L5h*/ + HU * 9 + HU * NTV + (DU + (fc ? 1 : 0)) * NTV + 8;
@@ -47,21 +49,26 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 }  // namespace A
 
 // ---------------- shape B: fp32 (UE 4, 1-KiB units) or split 16-bit (UE 8, 2-KiB) ---
+// bytes per sequence position per out tile are the same for both (256 B), so are the chunk counts
 namespace B {
-constexpr int CH_L0X = 27;
-constexpr int CH_HID = 16;
+constexpr int VPC = CHUNK_BYTES / 256;        // (sequence position, tile) pairs per chunk
+constexpr int CH_L0X = cdiv(XSEQ * NT, VPC);
+constexpr int CH_HID = cdiv(HSEQ * NT, VPC);
 constexpr int C_L0 = 0;
-constexpr int C_L1 = C_L0 + CH_L0X;           // 27
-constexpr int C_L5H = C_L1 + 4 * CH_HID;      // 91
-constexpr int C_L5X = C_L5H + CH_HID;         // 107
-constexpr int C_L6 = C_L5X + CH_L0X;          // 134
-constexpr int C_F = C_L6 + 2 * CH_HID;        // 166
-constexpr int C_ALPHA = C_F + CH_HID;         // 182
-constexpr int C_VF = C_ALPHA + 2;             // 184
-constexpr int C_VD = C_VF + 8;                // 192
-constexpr int CH_VD = 21;
-constexpr int C_RGB = C_VD + CH_VD;           // 213
-constexpr int NCHUNK = 214;
+constexpr int C_L1 = C_L0 + CH_L0X;
+constexpr int C_L5H = C_L1 + 4 * CH_HID;
+constexpr int C_L5X = C_L5H + CH_HID;
+constexpr int C_L6 = C_L5X + CH_L0X;
+constexpr int C_F = C_L6 + 2 * CH_HID;
+constexpr int C_ALPHA = C_F + CH_HID;
+constexpr int CH_ALPHA = cdiv(HSEQ, VPC);
+constexpr int C_VF = C_ALPHA + CH_ALPHA;
+constexpr int CH_VF = cdiv(HSEQ * NTV, VPC);
+constexpr int C_VD = C_VF + CH_VF;
+constexpr int CH_VD = cdiv((DSEQ + 8) * NTV, VPC);
+constexpr int C_RGB = C_VD + CH_VD;
+constexpr int NCHUNK = C_RGB + 1;
+static_assert(cdiv(DSEQ * NTV, VPC) == CH_VD, "view segment must take the same chunks with and without frame code");
 }  // namespace B
 
 }  // namespace pgp

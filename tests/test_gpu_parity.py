@@ -106,7 +106,7 @@ def _oracle_stage(g, cfg, quant):
     return ocfg, torch_weights(wc), torch_weights(wf)
 
 
-@pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 2e-2),
+@pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 4e-2),
                                             (PREC_FP16, "fp16", 5e-3)]
                          + ([(PREC_BF16X3, None, 3e-3), (PREC_FP16X3, None, 1e-3)] if X3 else []))
 def test_stage_eval_coarse(casters, prec, quant, tol):

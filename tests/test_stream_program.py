@@ -1,0 +1,204 @@
+"""CPU test of the host-side weight packer against a Python restatement of the kernels'
+stream program (pg_program.h / pg_eval16.hip / pg_eval32.hip): the packed stream is
+consumed chunk by chunk exactly as a wave does (enter a new chunk whenever the running
+unit index of a segment hits a multiple of units-per-chunk), every unit is multiplied as
+an MFMA A fragment with the lane-value sequences of pg_layout.h, and the result must be
+the oracle's MLP output.  No GPU needed: `pg_debug_pack` is host-only.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import anerf_oracle as orc
+from posegen_amd import _ffi, synthetic as syn
+from posegen_amd.config import PREC_BF16, PREC_FP16, PREC_FP32, RenderConfig, h36m_config, surreal_config
+from posegen_amd.raycaster import NET_TENSOR_ORDER
+from tests.helpers import oracle_cfg
+
+J, JH, LV, LD, W, NT, VW, NTV = 24, 12, 7, 4, 256, 8, 128, 4
+XSEQ, HSEQ, DSEQ_MAIN, DSEQ = 216, 128, 288, 328
+BT_FEAT, BT_ALPHA, BT_VIEW, BT_RGB = 64, 72, 73, 77
+
+
+def rho(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def xseq_channel(i, h):
+    sb, w = divmod(i, 72)
+    if w < 64:
+        jj, q = 4 * sb + w // 16, w % 16
+    else:
+        jj, q = 4 * sb + (w - 64) // 2, 16 + (w - 64) % 2
+    j = JH * h + jj
+    return q * J + j if q < 15 else 360 + 3 * j + (q - 15)
+
+
+def dseq_channel(i, h):
+    if i < DSEQ_MAIN:
+        blk, row = divmod(i, 8)
+        return row * 72 + 3 * (JH * h + blk // 3) + blk % 3
+    k = i - DSEQ_MAIN
+    return -1 if k >= 36 else 8 * 72 + 3 * (JH * h + k // 3) + k % 3
+
+
+def hseq_channel(i, h):
+    return 32 * (i // 16) + rho(i % 16, h)
+
+
+def pack(weights, cfg, prec):
+    lib = _ffi.load_library()
+    arrs = [np.ascontiguousarray(weights[k], dtype=np.float32) for k in NET_TENSOR_ORDER]
+    ptrs = (C.c_void_p * 24)(*[a.ctypes.data for a in arrs])
+    shp = (C.c_int64 * 48)()
+    for i, a in enumerate(arrs):
+        shp[2 * i], shp[2 * i + 1] = a.shape[0], (a.shape[1] if a.ndim == 2 else 1)
+    size, chunk = C.c_int64(), C.c_int32()
+    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(size), None, C.byref(chunk))
+    assert rc == 0, lib.pg_last_error(None)
+    buf = np.zeros(size.value, dtype=np.uint8)
+    bias = np.zeros(78 * 32, dtype=np.float32)
+    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, buf.ctypes.data, size.value, C.byref(size),
+                           bias.ctypes.data, C.byref(chunk))
+    assert rc == 0, lib.pg_last_error(None)
+    return buf, bias, chunk.value
+
+
+class Wave:
+    """A wave's view of the stream: chunks are entered strictly in order."""
+
+    def __init__(self, stream, chunk_bytes, prec):
+        self.s, self.cb, self.prec = stream, chunk_bytes, prec
+        self.chunk = -1
+        self.f32 = prec == PREC_FP32
+        self.ue = 4 if self.f32 else 8
+        self.upc = chunk_bytes // 1024
+
+    def unit(self, L):
+        """A fragment of unit L of the current segment -> [32 rows, 2 halves, ue] fp32."""
+        if L % self.upc == 0:
+            self.chunk += 1
+        off = self.chunk * self.cb + (L % self.upc) * 1024
+        raw = self.s[off:off + 1024].reshape(64, 16)
+        if self.f32:
+            v = raw.view(np.float32).reshape(64, 4)
+        elif self.prec == PREC_BF16:
+            v = (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(64, 8)
+        else:
+            v = raw.view(np.float16).astype(np.float32).reshape(64, 8)
+        return v.reshape(2, 32, self.ue).transpose(1, 0, 2)      # lane = 32*h + row
+
+    def mma(self, acc, L, o, bvals, u):
+        """acc[o] += A(unit L) x B, B = values [2, n, 32pts] of sequence positions u*ue.."""
+        a = self.unit(L)                                           # [row, h, e]
+        b = bvals[:, u * self.ue:(u + 1) * self.ue, :]             # [h, e, pt]
+        acc[o] += np.einsum("rhe,hep->rp", a, b)
+
+
+def q16(x, prec):
+    if prec == PREC_BF16:
+        return torch.tensor(x).to(torch.bfloat16).to(torch.float32).numpy()
+    if prec == PREC_FP16:
+        return torch.tensor(x).to(torch.float16).to(torch.float32).numpy()
+    return x
+
+
+def emulate(stream, bias, chunk_bytes, prec, x, cfg):
+    """x: [32 pts, 1080(+code16)] oracle input rows -> raw [32, 4] through the packed stream."""
+    wv = Wave(stream, chunk_bytes, prec)
+    shape_a = prec in (PREC_BF16, PREC_FP16)
+    ue = wv.ue
+
+    def seq_vals(fn, n, src):
+        v = np.zeros((2, n, 32), dtype=np.float32)
+        for h in range(2):
+            for i in range(n):
+                ch = fn(i, h)
+                if ch >= 0:
+                    v[h, i] = src[:, ch]
+        return q16(v, prec)
+
+    def bias_tile(t):
+        b = bias[t * 32:(t + 1) * 32].reshape(2, 16)
+        out = np.zeros((32, 1), dtype=np.float32)
+        for h in range(2):
+            for r in range(16):
+                out[rho(r, h), 0] = b[h, r]
+        return np.repeat(out, 32, axis=1)
+
+    def segment(no, kmajor, inputs, bias0, acc=None):
+        """inputs: list of (values [2,n,32], n).  Returns acc tiles [no][32,32]."""
+        if acc is None:
+            acc = [bias_tile(bias0 + o) for o in range(no)]
+        units = [(vals, u) for vals, n in inputs for u in range(n // ue)]
+        nu = len(units)
+        for L in range(nu * no):
+            ui, o = (L // no, L % no) if kmajor else (L % nu, L // nu)
+            wv.mma(acc, L, o, units[ui][0], units[ui][1])
+        return acc
+
+    def hidden_vals(tiles, relu=True):
+        act = np.concatenate(tiles, 0)                              # [channels, pts]
+        if relu:
+            act = np.maximum(act, 0)
+        return seq_vals(hseq_channel, len(tiles) * 16, act.T), act
+
+    km = not shape_a
+    xs = seq_vals(xseq_channel, XSEQ, x[:, :432])
+    tiles = segment(NT, True, [(xs, XSEQ)], 0)
+    hv, _ = hidden_vals(tiles)
+    for l in range(1, 5):
+        tiles = segment(NT, km, [(hv, HSEQ)], l * NT)
+        hv, _ = hidden_vals(tiles)
+    tiles = segment(NT, km, [(hv, HSEQ)], 5 * NT)
+    tiles = segment(NT, True, [(xs, XSEQ)], 0, acc=tiles)
+    hv, _ = hidden_vals(tiles)
+    for l in (6, 7):
+        tiles = segment(NT, km, [(hv, HSEQ)], l * NT)
+        hv, _ = hidden_vals(tiles)
+    if shape_a:
+        fa = segment(NT + 1, False, [(hv, HSEQ)], BT_FEAT)
+        sigma = fa[NT][0]
+        feat = fa[:NT]
+    else:
+        feat = segment(NT, True, [(hv, HSEQ)], BT_FEAT)
+        sigma = segment(1, True, [(hv, HSEQ)], BT_ALPHA)[0][0]
+    fv, _ = hidden_vals(feat, relu=False)
+    vt = segment(NTV, km, [(fv, HSEQ)], BT_VIEW)
+    ins = [(seq_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
+    if cfg.framecode_ch:
+        ins.append((seq_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
+    vt = segment(NTV, True, ins, 0, acc=vt)
+    gv, _ = hidden_vals(vt)
+    rgb = segment(1, km, [(gv, VW // 2)], BT_RGB)[0]
+    return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
+
+
+@pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 2e-2), (PREC_FP16, "fp16", 4e-3)])
+@pytest.mark.parametrize("fc", [False, True])
+def test_packed_stream_reproduces_mlp(prec, quant, tol, fc):
+    try:
+        _ffi.load_library()
+    except _ffi.HipLibraryError as e:
+        pytest.skip(str(e))
+    cfg = h36m_config() if fc else surreal_config()
+    w = syn.make_weights(cfg, 3)
+    stream, bias, chunk_bytes = pack(w, cfg, prec)
+    rng = np.random.RandomState(0)
+    x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
+    x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)     # cutoff-weighted magnitudes
+    ocfg = oracle_cfg(cfg, 79.6, 79.6)
+    ocfg.quant = quant
+    tw = {k: torch.tensor(v) for k, v in w.items()}
+    if fc:
+        idx = rng.randint(0, cfg.n_framecodes, size=(32, 1)).astype(np.float32)
+        ref = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1)), tw, ocfg).numpy()
+        x_em = np.concatenate([x, w["framecodes.codes.weight"][idx[:, 0].astype(int)]], 1)
+    else:
+        ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
+        x_em = x
+    raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg)
+    assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
+    np.testing.assert_allclose(raw, ref, rtol=0, atol=tol * max(1.0, float(np.abs(ref).max()) / 10))

@@ -13,7 +13,7 @@ c = HipRayCaster.from_weights(cfg, wc, wf, tv, td, device="cuda:0", precision=0)
 rb, skts = torch.tensor(g["ray_batch"]), torch.tensor(g["skts"])
 z = torch.tensor(g["z_coarse"]); n, S = z.shape
 pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]
-for prec, quant in ((0, None), (2, "bf16x3"), (4, "fp16x3"), (1, "bf16"), (3, "fp16")):
+for prec, quant in ((0, None), (1, "bf16"), (3, "fp16")):
     c.renderer.set_precision(prec)
     raw = c.renderer.stage_eval(0, rb, z, skts).cpu()
     for q in (None, quant):
