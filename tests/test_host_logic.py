@@ -1,0 +1,131 @@
+"""CPU tests of the host side: reference-mirroring geometry against the golden vectors,
+the C-ABI surface of the shared library, the multi-GPU frame partition and its gather
+(gloo, world_size 2)."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from posegen_amd import _ffi
+from posegen_amd.dist import partition_frames
+from posegen_amd.rays import get_rays, kp_to_valid_rays
+from posegen_amd.skeleton import bones_to_pose, get_smpl_l2ws
+from tests.helpers import load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kinematics_matches_reference_golden():
+    g = load_golden("kinematics")
+    kps, skts, l2ws = bones_to_pose(g["bones"], g["rest_pose"])
+    np.testing.assert_allclose(l2ws, g["l2ws"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(kps, g["kps"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(skts, g["skts"], rtol=0, atol=1e-10)
+    assert get_smpl_l2ws(g["bones"][0], g["rest_pose"]).dtype == np.float64
+
+
+def test_valid_rays_matches_reference_golden():
+    g = load_golden("valid_rays")
+    H, W = int(g["H"]), int(g["W"])
+    rays, vids, cyls, boxes = kp_to_valid_rays(torch.tensor(g["c2ws"]), H, W, g["focals"],
+                                               kps=torch.tensor(g["kps"]), ext_scale=0.001)
+    np.testing.assert_array_equal(cyls.numpy(), g["cyls"])
+    for i in range(len(rays)):
+        assert np.array_equal(np.array([boxes[i][0], boxes[i][1]]), g["boxes"][i])      # integer bbox: exact
+        assert len(vids[i]) == int(g[f"n_valid_{i}"])
+        assert np.array_equal(vids[i][:8].numpy(), g[f"vid_head_{i}"])
+        assert np.array_equal(vids[i][-8:].numpy(), g[f"vid_tail_{i}"])
+        np.testing.assert_array_equal(rays[i][0][:8].numpy(), g[f"rays_o_head_{i}"])
+        np.testing.assert_array_equal(rays[i][1][:8].numpy(), g[f"rays_d_head_{i}"])
+        np.testing.assert_array_equal(rays[i][1][-8:].numpy(), g[f"rays_d_tail_{i}"])
+
+
+def test_get_rays_full_frame_equals_box_rays():
+    g = load_golden("valid_rays")
+    H, W = int(g["H"]), int(g["W"])
+    rays, vids, _, _ = kp_to_valid_rays(torch.tensor(g["c2ws"][:1]), H, W, g["focals"][:1],
+                                        kps=torch.tensor(g["kps"][:1]), ext_scale=0.001)
+    ro, rd = get_rays(H, W, g["focals"][0], torch.tensor(g["c2ws"][0]))
+    assert torch.equal(rd.reshape(-1, 3)[vids[0]], rays[0][1])
+
+
+def test_library_exports_every_symbol_of_the_header():
+    try:
+        lib = _ffi.load_library()
+    except _ffi.HipLibraryError as e:
+        pytest.fail(f"library missing: {e} (run __graft_entry__.build())")
+    hdr = open(os.path.join(REPO, "include", "posegen_hip.h")).read()
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pg_handle"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/posegen_hip.h but not exported"
+        assert name in _ffi.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert lib.pg_abi_version() == _ffi.PG_ABI_VERSION
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_ffi.HipLibraryError):
+        _ffi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_no_gpu_means_error_not_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from posegen_amd.config import surreal_config
+    from posegen_amd.raycaster import HipRenderer
+    with pytest.raises((_ffi.HipLibraryError, _ffi.PgError, RuntimeError)):
+        HipRenderer(surreal_config(), "cuda:0")
+
+
+def test_partition_frames_balanced_and_complete():
+    rng = np.random.RandomState(0)
+    for world in (1, 2, 3, 8):
+        for F in (1, 2, 7, 20):
+            n = rng.randint(100, 5000, size=F)
+            parts = partition_frames(n, world)
+            assert sorted(f for p in parts for f in p) == list(range(F))
+            loads = [int(sum(n[f] for f in p)) for p in parts]
+            if F >= world:
+                assert max(loads) - min(loads) <= int(n.max())
+    assert partition_frames([10] * 20, 8) == partition_frames([10] * 20, 8)
+
+
+_GLOO_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from posegen_amd.dist import gather_frames, partition_frames
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_rays = [300, 100, 250, 50, 400]
+parts = partition_frames(n_rays, world)
+H = W = 4
+mine = parts[rank]
+local = torch.stack([torch.full((H, W, 5), float(f + 1)) for f in mine]) if mine else torch.zeros(0, H, W, 5)
+full = gather_frames(local, mine, parts, len(n_rays))
+assert full.shape == (5, H, W, 5)
+for f in range(5):
+    assert torch.all(full[f] == f + 1), (rank, f)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gather_frames_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), REPO]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
