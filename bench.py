@@ -169,6 +169,16 @@ def main():
                      "end_to_end_frac": rays_s / world * flops_pt * cfg.evals_per_ray() / 1e12 / peak},
     }
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
+    # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r1_traffic.json);
+    # bench.py cannot run the profiler on itself, so the committed measurement is attached.
+    tpath = os.path.join(REPO, "profiles", "r1_traffic.json")
+    if a.prec == "bf16" and H == 512 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        result["roofline"]["traffic"] = tj["hbm_bytes"]
+        result["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/r1_traffic.json)"
+        result["roofline"]["algorithmic_bytes_per_launch"] = tj["algorithmic_bytes"]
+
     sel = ref = None
     if not a.no_cpu_baseline:
         base, sel, ref = cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, a.cpu_rays)

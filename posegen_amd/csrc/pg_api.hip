@@ -18,6 +18,7 @@
 extern "C" {
 int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
+int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
 int pg_eval32_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
@@ -174,7 +175,8 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
     a.n_iters = (int)iters;
-    const int grid = (int)(iters < h->n_cu ? iters : h->n_cu);
+    const long long max_wg = (long long)h->n_cu * (sa ? pg_eval16_wgs_per_cu() : 1);
+    const int grid = (int)(iters < max_wg ? iters : max_wg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         auto get = [&](hipEvent_t& ev) {

@@ -64,6 +64,7 @@ struct Stream {
     uint32_t next_off;     // byte offset in the stream of the next chunk to fetch
     uint32_t fill_slot;    // ring slot that fetch goes to
     uint32_t rd_off;       // this lane's byte offset into the ring for the current chunk
+    uint32_t ring_lds;     // LDS byte address of the ring (for asm ds_read)
 
     __device__ __forceinline__ void prefetch_next() {
         const uint8_t* src = wstream + next_off + (wave * (PER * 1024) + lane * 16);
@@ -82,10 +83,24 @@ struct Stream {
         for (int i = 0; i < DEPTH; ++i) prefetch_next();
         rd_off = (uint32_t)(NSLOT - 1) * CHUNK_BYTES + lane * 16;   // advanced by the first enter()
     }
+#if defined(PG_STAMPS)
+    unsigned long long t_vm = 0, t_bar = 0;
+#endif
     __device__ __forceinline__ void enter(int /*chunk index, documentation only*/) {
+#if defined(PG_STAMPS)
+        unsigned long long s0, s1, s2;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0)::"memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2)::"memory");
+        t_vm += s1 - s0;
+        t_bar += s2 - s1;
+#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         prefetch_next();
         rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES
                                                                                   : rd_off + CHUNK_BYTES;
@@ -93,6 +108,23 @@ struct Stream {
     }
     __device__ __forceinline__ const uint8_t* at(int /*chunk*/, int byte_off) const {
         return ring + byte_off + rd_off;
+    }
+    // asynchronous ds_read_b128 of unit `pos` (compile-time) of the current chunk; the caller
+    // retires it with a counted s_waitcnt lgkmcnt (hipcc does not see this load)
+    template <typename R>
+    __device__ __forceinline__ void issue(R& dst, int pos) const {
+        const unsigned addr = ring_lds + rd_off;
+        switch (pos) {   // the DS offset field wants a literal: pos is constant after unrolling
+#define PG_ISSUE_CASE(P) case P: asm volatile("ds_read_b128 %0, %1 offset:" #P "*1024" : "=v"(dst) : "v"(addr)); break;
+            PG_ISSUE_CASE(0) PG_ISSUE_CASE(1) PG_ISSUE_CASE(2) PG_ISSUE_CASE(3) PG_ISSUE_CASE(4) PG_ISSUE_CASE(5)
+            PG_ISSUE_CASE(6) PG_ISSUE_CASE(7) PG_ISSUE_CASE(8) PG_ISSUE_CASE(9) PG_ISSUE_CASE(10) PG_ISSUE_CASE(11)
+            PG_ISSUE_CASE(12) PG_ISSUE_CASE(13) PG_ISSUE_CASE(14) PG_ISSUE_CASE(15) PG_ISSUE_CASE(16) PG_ISSUE_CASE(17)
+            PG_ISSUE_CASE(18) PG_ISSUE_CASE(19) PG_ISSUE_CASE(20) PG_ISSUE_CASE(21) PG_ISSUE_CASE(22) PG_ISSUE_CASE(23)
+            PG_ISSUE_CASE(24) PG_ISSUE_CASE(25) PG_ISSUE_CASE(26) PG_ISSUE_CASE(27) PG_ISSUE_CASE(28) PG_ISSUE_CASE(29)
+            PG_ISSUE_CASE(30) PG_ISSUE_CASE(31)
+#undef PG_ISSUE_CASE
+            default: __builtin_unreachable();
+        }
     }
     // before the wave exits: no DMA may be left in flight
     __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -103,6 +135,14 @@ __device__ __forceinline__ f32x16 load_bias(const float* bias, int tile, int h) 
     const float4 a = p[0], b = p[1], c = p[2], d = p[3];
     f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     return r;
+}
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() would also wait vmcnt(0), i.e.
+// drain the weight-stream DMA that is deliberately in flight across pass boundaries.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // LDS carve-up (bytes) shared by both kernel shapes
@@ -217,7 +257,7 @@ __device__ __forceinline__ void ray_table_phase1(const EvalArgs& a, float* rtab,
 
 // View-direction table: e = normalize(R_j d) per joint (encoders.py:25-37,172-193), rows
 // (e, sin e, cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e | cos 8e) in D-sequence order.
-template <int NTHREADS>
+template <int NTHREADS, bool FAST>
 __device__ __forceinline__ void ray_table_phase2(float* rtab, int nr) {
     for (int idx = threadIdx.x; idx < nr * J; idx += NTHREADS) {
         const int rr = idx / J, j = idx - rr * J;
@@ -228,14 +268,20 @@ __device__ __forceinline__ void ray_table_phase2(float* rtab, int nr) {
         e[0] = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
         e[1] = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
         e[2] = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
-        const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
+        const float den = fmaxf(pg_sqrt<FAST>(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
         const int h = j / JH, jj = j - h * JH;
         float* tab = slot + SLOT_DTAB + h * DSEQ;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float ev = e[c] / den;
+            const float ev = pg_div<FAST>(e[c], den);
             float s, co;
-            sincosf(ev, &s, &co);
+            if (FAST) {
+                const float rev = ev * 0.15915494309189535f;
+                s = __builtin_amdgcn_sinf(rev);
+                co = __builtin_amdgcn_cosf(rev);
+            } else {
+                sincosf(ev, &s, &co);
+            }
             float* m = tab + (jj * 3 + c) * 8;
             m[0] = ev;
 #pragma unroll

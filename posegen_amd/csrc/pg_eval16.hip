@@ -18,7 +18,10 @@
 namespace pgd {
 using namespace pgp::A;
 
-constexpr int NWAVE = 8;
+#ifndef PG_A_WAVES
+#define PG_A_WAVES 8
+#endif
+constexpr int NWAVE = PG_A_WAVES;          // 8: one workgroup per CU; 4: two independent workgroups per CU
 constexpr int NTHR = NWAVE * 64;
 constexpr int PTS = NWAVE * 32;     // points per workgroup pass
 
@@ -48,40 +51,84 @@ template <> struct Op<f16x8> {
 
 using Stream16 = Stream<NWAVE, NCHUNK>;
 
+#ifndef PG_ASYNC_X
+#define PG_ASYNC_X true       // hand-pipelined ring reads in the x segments
+#endif
+#ifndef PG_ASYNC_VD
+#define PG_ASYNC_VD true      // ... in the view-direction segment
+#endif
+
 template <typename V>
 __device__ __forceinline__ V unit_of(Stream16& st, int c, int pos) {
     return __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(c, pos * UNIT_BYTES)));
 }
 
-// one B fragment against NO out tiles, k-major segment starting at chunk cbase
-template <typename V, int NO>
-__device__ __forceinline__ void mma_row(f32x16* acc, Stream16& st, int cbase, int uu, V b) {
-#pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        const int L = uu * NO + o;
-        if (L % UPC == 0) st.enter(cbase + L / UPC);
-        acc[o] = Op<V>::mfma(unit_of<V>(st, cbase + L / UPC, L % UPC), b, acc[o]);
+// Software pipeline of the A operand.  Left to hipcc, every ring read is sunk next to its MFMA
+// (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma): the whole LDS latency is exposed 1700 times per
+// pass and the MFMA pipe idles ~45 %.  The reads are therefore issued by inline asm, two units
+// ahead into a 3-register-set rotation, and retired by COUNTED lgkmcnt waits (the asm is
+// invisible to hipcc's own waitcnt bookkeeping, whose waits for its own LDS reads only become
+// more conservative).  The lookahead never crosses a chunk boundary (the next chunk is only
+// readable after its enter(), which also drains lgkmcnt).
+typedef __attribute__((ext_vector_type(4))) unsigned a128;
+template <typename V> struct APipe { a128 r[3]; };
+
+template <int YOUNGER>
+__device__ __forceinline__ void lds_retire(a128& r) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(YOUNGER));
+}
+
+// A fragment of unit L (compile-time after unrolling) of a segment with T units.
+// ASYNC = hand-pipelined asm reads; only where register pressure is low enough that hipcc
+// never copies or spills a pipe register between issue and retire (tools/audit_asm_loads.py
+// checks the compiled code).  Otherwise a plain (compiler-scheduled) read.
+template <typename V, int T, bool ASYNC>
+__device__ __forceinline__ V next_a(APipe<V>& p, Stream16& st, int L) {
+    if (!ASYNC) {
+        if (L % UPC == 0) st.enter(L / UPC);
+        return unit_of<V>(st, 0, L % UPC);
     }
+    const bool has1 = L + 1 < T && (L + 1) / UPC == L / UPC;
+    const bool has2 = L + 2 < T && (L + 2) / UPC == L / UPC;
+    if (L % UPC == 0) {
+        st.enter(L / UPC);
+        st.issue(p.r[L % 3], L % UPC);
+        if (has1) st.issue(p.r[(L + 1) % 3], (L + 1) % UPC);
+    }
+    if (has2) st.issue(p.r[(L + 2) % 3], (L + 2) % UPC);
+    if (has2) lds_retire<2>(p.r[L % 3]);
+    else if (has1) lds_retire<1>(p.r[L % 3]);
+    else lds_retire<0>(p.r[L % 3]);
+    return __builtin_bit_cast(V, p.r[L % 3]);
+}
+
+// one B fragment against NO out tiles; unit row uu of a k-major segment with T units
+template <typename V, int NO, int T, bool ASYNC>
+__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V>& p, Stream16& st, int uu, V b) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC>(p, st, uu * NO + o), b, acc[o]);
 }
 
 // acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
 template <typename V>
 __device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, const float* slot,
                                           const float* cut, float tau, float px, float py, float pz, int h) {
-#pragma unroll
+    APipe<V> p;
+    constexpr int T = XU * NT;
+#pragma clang loop unroll(full)
     for (int sb = 0; sb < 3; ++sb) {
         float lo[8];
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int k = 0; k < 4; ++k) {
             const int jj = 4 * sb + k;
             float x[18];
             joint_values<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
             lo[2 * k] = x[16];
             lo[2 * k + 1] = x[17];
-            mma_row<V, NT>(acc, st, cbase, sb * 9 + 2 * k, Op<V>::cvt(x));
-            mma_row<V, NT>(acc, st, cbase, sb * 9 + 2 * k + 1, Op<V>::cvt(x + 8));
+            mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k, Op<V>::cvt(x));
+            mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k + 1, Op<V>::cvt(x + 8));
         }
-        mma_row<V, NT>(acc, st, cbase, sb * 9 + 8, Op<V>::cvt(lo));
+        mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 8, Op<V>::cvt(lo));
     }
 }
 
@@ -113,26 +160,32 @@ __device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool 
 }
 
 // acc += W[tile o] * fin over the HU hidden units; out-tile-major segment starting at cbase
-template <typename V>
-__device__ __forceinline__ void row_tile(f32x16& acc, Stream16& st, int cbase, int o, const V* fin) {
+template <typename V, int T, bool ASYNC>
+__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V>& p, Stream16& st, int o, const V* fin) {
 #pragma unroll
-    for (int u = 0; u < HU; ++u) {
-        const int L = o * HU + u;
-        if (L % UPC == 0) st.enter(cbase + L / UPC);
-        acc = Op<V>::mfma(unit_of<V>(st, cbase + L / UPC, L % UPC), fin[u], acc);
-    }
+    for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(next_a<V, T, ASYNC>(p, st, o * HU + u), fin[u], acc);
 }
 
-// fout = relu(W fin + b), out-tile-major segment starting at chunk cbase
+// fout = relu(W fin + b), out-tile-major segment starting at chunk cbase.
+// The ReLU + 16-bit packing of tile o-1 (VALU, needs that tile's last MFMA to retire) is placed
+// after the first MFMAs of tile o, so it runs under them instead of draining the MFMA pipe.
 template <typename V>
 __device__ __forceinline__ void hidden_layer(const V* fin, V* fout, Stream16& st, int cbase,
                                              const float* bias, int tile0, int h) {
+    APipe<V> p;
+    f32x16 prev;
 #pragma unroll
     for (int o = 0; o < NT; ++o) {
         f32x16 acc = load_bias(bias, tile0 + o, h);
-        row_tile<V>(acc, st, cbase, o, fin);
-        relu_pack<V>(acc, fout[2 * o], fout[2 * o + 1], true);
+        constexpr int T = HU * NT;
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            acc = Op<V>::mfma(next_a<V, T, true>(p, st, o * HU + u), fin[u], acc);
+            if (u == 3 && o > 0) relu_pack<V>(prev, fout[2 * (o - 1)], fout[2 * (o - 1) + 1], true);
+        }
+        prev = acc;
     }
+    relu_pack<V>(prev, fout[2 * (NT - 1)], fout[2 * (NT - 1) + 1], true);
 }
 
 // debug: write a fragment array (H-sequence order) as floats to dbg[pt][256]
@@ -146,6 +199,12 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
     }
 }
 
+#if defined(PG_STAMPS)
+#define PG_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; } while (0)
+#else
+#define PG_STAMP(k) do {} while (0)
+#endif
+
 template <typename V, bool FC>
 __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -154,22 +213,27 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u};
+    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
     st.start();
 
+#if defined(PG_STAMPS)
+    unsigned long long stamps[12];
+#endif
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        PG_STAMP(0);
         const long long p0 = (long long)it * PTS;
         const long long plast = min(p0 + PTS - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
-        __syncthreads();
+        lds_barrier();                          // previous pass is done with the table
         ray_table_phase1<NTHR>(a, rtab, r0, nr);
-        __syncthreads();
-        ray_table_phase2<NTHR>(rtab, nr);
-        __syncthreads();
+        lds_barrier();
+        ray_table_phase2<NTHR, true>(rtab, nr);
+        lds_barrier();
 
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;
@@ -181,6 +245,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const float py = __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
         const float pz = __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
 
+        PG_STAMP(1);
         V fa[HU], fb[HU];
         {   // ---- layer 0: K = 432 generated on the fly, all 8 out tiles live ----
             f32x16 acc[NT];
@@ -196,43 +261,52 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
 #pragma unroll
             for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fa[2 * o], fa[2 * o + 1], true);
         }
+        PG_STAMP(2);
         // ---- layers 1..4 ----
         hidden_layer<V>(fa, fb, st, C_L1 + 0 * CH_HID, bias, BT_LAYER0 + 1 * NT, h);
         hidden_layer<V>(fb, fa, st, C_L1 + 1 * CH_HID, bias, BT_LAYER0 + 2 * NT, h);
         hidden_layer<V>(fa, fb, st, C_L1 + 2 * CH_HID, bias, BT_LAYER0 + 3 * NT, h);
         hidden_layer<V>(fb, fa, st, C_L1 + 3 * CH_HID, bias, BT_LAYER0 + 4 * NT, h);
+        PG_STAMP(3);
         {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
             f32x16 acc[NT];
+            APipe<V> p5;
 #pragma unroll
             for (int o = 0; o < NT; ++o) {
                 acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
-                row_tile<V>(acc[o], st, C_L5H, o, fa);
+                row_tile<V, HU * NT, PG_ASYNC_X>(acc[o], p5, st, o, fa);
             }
             x_segment<V>(acc, st, C_L5X, slot, cut, a.tau_v, px, py, pz, h);
 #pragma unroll
             for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fb[2 * o], fb[2 * o + 1], true);
         }
+        PG_STAMP(4);
         hidden_layer<V>(fb, fa, st, C_L6 + 0 * CH_HID, bias, BT_LAYER0 + 6 * NT, h);
         hidden_layer<V>(fa, fb, st, C_L6 + 1 * CH_HID, bias, BT_LAYER0 + 7 * NT, h);
+        PG_STAMP(5);
         // ---- heads: feature (no activation) and sigma ----
         float sigma;
+        APipe<V> pfa;
 #pragma unroll
         for (int o = 0; o < NT + 1; ++o) {
             f32x16 acc = load_bias(bias, BT_FEAT + o, h);      // tile 8 = BT_ALPHA
-            row_tile<V>(acc, st, C_FA, o, fb);
+            row_tile<V, HU * (NT + 1), true>(acc, pfa, st, o, fb);
             if (o < NT) relu_pack<V>(acc, fa[2 * o], fa[2 * o + 1], false);
             else sigma = acc[0];
         }
+        PG_STAMP(6);
         dump_frags<V, HU>(a, 7, gp, valid, fb, h);
         dump_frags<V, HU>(a, 8, gp, valid, fa, h);
         // ---- view layer: [feature(256), xd(648) (, code16)] -> 128, relu ----
         V fg[HU / 2];
         {
             f32x16 acc[NTV];
+            APipe<V> pv, pd;
+            constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
                 acc[o] = load_bias(bias, BT_VIEW + o, h);
-                row_tile<V>(acc[o], st, C_VF, o, fa);
+                row_tile<V, HU * NTV, true>(acc[o], pv, st, o, fa);
             }
             float wd[JH];
 #pragma unroll
@@ -240,7 +314,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
                 wd[jj] = cutoff_weight<true>(joint_dist<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
                                        a.tau_d, cut[J + JH * h + jj]);
             const float* tab = slot + SLOT_DTAB + h * DSEQ;
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int uu = 0; uu < DU; ++uu) {
                 const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
                 const float4 t1 = *reinterpret_cast<const float4*>(tab + uu * 8 + 4);
@@ -250,25 +324,37 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
                     const int k = uu < JH * 3 ? uu / 3 : (8 * (uu - JH * 3) + e) / 3;
                     x[e] = k < JH ? x[e] * wd[k] : 0.0f;
                 }
-                mma_row<V, NTV>(acc, st, C_VD, uu, Op<V>::cvt(x));
+                mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, uu, Op<V>::cvt(x));
             }
             if (FC) {
                 const float4 t0 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h);
                 const float4 t1 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h + 4);
                 const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                mma_row<V, NTV>(acc, st, C_VD, DU, Op<V>::cvt(x));
+                mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, DU, Op<V>::cvt(x));
             }
 #pragma unroll
             for (int o = 0; o < NTV; ++o) relu_pack<V>(acc[o], fg[2 * o], fg[2 * o + 1], true);
         }
+        PG_STAMP(7);
         dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
         // ---- rgb head ----
-        st.enter(C_RGB);
         f32x16 acc = load_bias(bias, BT_RGB, h);
+        {
+            APipe<V> pr;
 #pragma unroll
-        for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(unit_of<V>(st, C_RGB, u), fg[u], acc);
+            for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(next_a<V, HU / 2, true>(pr, st, u), fg[u], acc);
+        }
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(acc[0], acc[1], acc[2], sigma);
+        PG_STAMP(8);
+#if defined(PG_STAMPS)
+        if (a.dbg && a.dbg_stage == 99 && lane == 0 && it < 64) {
+            for (int k = 0; k < 9; ++k) reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + k] = stamps[k];
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + 9] = st.t_vm;
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + 10] = st.t_bar;
+            st.t_vm = 0; st.t_bar = 0;
+        }
+#endif
     }
     st.drain();
 }
@@ -299,3 +385,4 @@ extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode,
 }
 
 extern "C" int pg_eval16_points_per_pass(void) { return pgd::PTS; }
+extern "C" int pg_eval16_wgs_per_cu(void) { return 8 / pgd::NWAVE; }

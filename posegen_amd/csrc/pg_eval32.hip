@@ -151,7 +151,8 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u};
+    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR_B) bias[i] = a.bias[i];
     if (tid < 48) cut[tid] = a.cutoff[tid];
@@ -162,11 +163,11 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         const long long plast = min(p0 + PTS_B - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
-        __syncthreads();
+        lds_barrier();                          // previous pass is done with the table
         ray_table_phase1<NTHR_B>(a, rtab, r0, nr);
-        __syncthreads();
-        ray_table_phase2<NTHR_B>(rtab, nr);
-        __syncthreads();
+        lds_barrier();
+        ray_table_phase2<NTHR_B, false>(rtab, nr);
+        lds_barrier();
 
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;

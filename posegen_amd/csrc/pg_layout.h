@@ -99,7 +99,10 @@ constexpr int SLOT_D = SLOT_O + 3;            // 947
 constexpr int SLOT_CAM = SLOT_D + 3;          // 950
 constexpr int SLOT_CODE = 952;                // 16 floats
 constexpr int SLOT_FLOATS = 976;              // multiple of 4
-constexpr int MAXR = 9;                       // rays overlapped by one workgroup pass
+#ifndef PG_MAXR
+#define PG_MAXR 9
+#endif
+constexpr int MAXR = PG_MAXR;                 // rays overlapped by one workgroup pass
 
 // bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1)
 constexpr int BT_LAYER0 = 0;

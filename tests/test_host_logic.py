@@ -129,3 +129,15 @@ def test_gather_frames_gloo_world2(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_inline_asm_ring_reads_are_not_touched_by_the_compiler():
+    """The 16-bit kernel issues its ring reads by inline asm and retires them with counted
+    waits; the compiled code must never copy / spill such a register in between."""
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    out = subprocess.run(["make", "-C", os.path.join(REPO, "posegen_amd", "csrc"), "audit"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "AUDIT OK" in out.stdout
