@@ -49,11 +49,18 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 #ifndef PG_RING_SLOTS
 #define PG_RING_SLOTS 3
 #endif
-template <int NWAVE, int NCHUNK_>
+#ifndef PG_DMA_BASE
+#define PG_DMA_BASE 0         // first DMA wave when only a subset of the waves refills the ring
+#endif
+// Only the first NDMA waves of the workgroup issue the DMA (PER pieces each per chunk); the
+// others just synchronise.  The oldest wave of each SIMD wins issue arbitration and reaches
+// every chunk barrier early: giving those waves all of the refill work (NDMA = NWAVE/2) moves
+// its issue cost off the critical wave of the SIMD.
+template <int NWAVE, int NCHUNK_, int NDMA = NWAVE>
 struct Stream {
     static constexpr int NSLOT = PG_RING_SLOTS;
     static constexpr int DEPTH = NSLOT - 1;
-    static constexpr int PER = CHUNK_BYTES / 1024 / NWAVE;   // DMA instructions per wave per chunk
+    static constexpr int PER = CHUNK_BYTES / 1024 / NDMA;    // DMA instructions per DMA wave per chunk
     const uint8_t* wstream;
     uint8_t* ring;
     int wave, lane;
@@ -66,11 +73,15 @@ struct Stream {
     uint32_t rd_off;       // this lane's byte offset into the ring for the current chunk
     uint32_t ring_lds;     // LDS byte address of the ring (for asm ds_read)
 
+    __device__ __forceinline__ bool dma_wave() const { return NDMA == NWAVE || (wave >= dma_base() && wave < dma_base() + NDMA); }
+    static constexpr int dma_base() { return NDMA == NWAVE ? 0 : PG_DMA_BASE; }
     __device__ __forceinline__ void prefetch_next() {
-        const uint8_t* src = wstream + next_off + (wave * (PER * 1024) + lane * 16);
-        uint8_t* dst = ring + fill_slot * CHUNK_BYTES + wave * (PER * 1024);
+        const uint8_t* src = wstream + next_off + ((wave - dma_base()) * (PER * 1024) + lane * 16);
+        uint8_t* dst = ring + fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
+        if (dma_wave()) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
+            for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
+        }
         next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
         fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
         asm volatile("" : "+s"(next_off), "+s"(fill_slot));
@@ -105,6 +116,29 @@ struct Stream {
         rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES
                                                                                   : rd_off + CHUNK_BYTES;
         asm volatile("" : "+v"(rd_off)::"memory");
+    }
+    // Split form of enter(): the same waits and barrier, but the refill of the freed slot is
+    // left to the caller, who issues its PER pieces one at a time with piece(i) spread over
+    // the units of the chunk just entered (all PER before the next enter: the vmcnt count
+    // relies on it).  Issued as one burst right after the barrier, the 8 waves' pieces queue up
+    // in the texture addresser and every wave stalls on the issue.
+    uint32_t cur_src, cur_dst;   // stream byte offset / ring byte offset of this wave's share
+    __device__ __forceinline__ void enter_split() {
+        if (dma_wave()) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_src = next_off + (wave - dma_base()) * (PER * 1024);
+        cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
+        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
+        asm volatile("" : "+s"(next_off), "+s"(fill_slot), "+s"(cur_src), "+s"(cur_dst));
+        rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES
+                                                                                  : rd_off + CHUNK_BYTES;
+        asm volatile("" : "+v"(rd_off)::"memory");
+    }
+    __device__ __forceinline__ void piece(int i) const {
+        const uint8_t* sbase = wstream + (cur_src + i * 1024);      // wave-uniform
+        if (dma_wave()) glds16(sbase + (uint32_t)(lane * 16), ring + cur_dst + i * 1024);
     }
     __device__ __forceinline__ const uint8_t* at(int /*chunk*/, int byte_off) const {
         return ring + byte_off + rd_off;

@@ -49,7 +49,24 @@ template <> struct Op<f16x8> {
     }
 };
 
-using Stream16 = Stream<NWAVE, NCHUNK>;
+#ifndef PG_SPREAD_DMA
+#define PG_SPREAD_DMA 1       // weight-ring refill spread over the chunk (Stream::enter_split)
+#endif
+#ifndef PG_DMA_PHASE
+#define PG_DMA_PHASE 2
+#endif
+#ifndef PG_DMA_WAVES
+#define PG_DMA_WAVES 8
+#endif
+using Stream16 = Stream<NWAVE, NCHUNK, PG_DMA_WAVES>;
+static_assert(PG_DMA_WAVES == NWAVE || PG_SPREAD_DMA, "the bulk enter() waits vmcnt on every wave");
+
+__device__ __forceinline__ const float* opaque_ptr(const float* p) {
+    // LDS pointers are 32-bit offsets; keep the value in one VGPR the optimizer cannot split
+    unsigned v = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+    asm volatile("" : "+v"(v));
+    return (const float*)(const __attribute__((address_space(3))) float*)(uintptr_t)v;
+}
 
 #ifndef PG_ASYNC_X
 #define PG_ASYNC_X true       // hand-pipelined ring reads in the x segments
@@ -71,49 +88,84 @@ __device__ __forceinline__ V unit_of(Stream16& st, int c, int pos) {
 // more conservative).  The lookahead never crosses a chunk boundary (the next chunk is only
 // readable after its enter(), which also drains lgkmcnt).
 typedef __attribute__((ext_vector_type(4))) unsigned a128;
-template <typename V> struct APipe { a128 r[3]; };
+#ifndef PG_EARLY_RETIRE
+#define PG_EARLY_RETIRE 0
+#endif
+#ifndef PG_PIPE_H
+#define PG_PIPE_H 3           // register sets of the A pipe in the register-light segments (hidden layers, heads)
+#endif
+#ifndef PG_PIPE_X
+#define PG_PIPE_X 3           // ... in the segments that hold 8 (x) or 4 (view) accumulator tiles
+#endif
+template <typename V, int NS = PG_PIPE_H> struct APipe { a128 r[NS]; };
+template <typename V> using APipeX = APipe<V, PG_PIPE_X>;
 
-template <int YOUNGER>
-__device__ __forceinline__ void lds_retire(a128& r) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(YOUNGER));
+__device__ __forceinline__ void lds_retire(a128& r, int younger) {
+    switch (younger) {   // constant after unrolling
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r)); break;
+        default: __builtin_unreachable();
+    }
 }
 
-// A fragment of unit L (compile-time after unrolling) of a segment with T units.
-// ASYNC = hand-pipelined asm reads; only where register pressure is low enough that hipcc
-// never copies or spills a pipe register between issue and retire (tools/audit_asm_loads.py
-// checks the compiled code).  Otherwise a plain (compiler-scheduled) read.
-template <typename V, int T, bool ASYNC>
-__device__ __forceinline__ V next_a(APipe<V>& p, Stream16& st, int L) {
+// A fragment of unit L (compile-time after unrolling) of a segment with T units: NS register
+// sets, reads issued NS-1 units ahead.  ASYNC = false: a plain (compiler-scheduled) read.
+template <typename V, int T, bool ASYNC, int NS>
+__device__ __forceinline__ V next_a(APipe<V, NS>& p, Stream16& st, int L) {
+    constexpr int PER = Stream16::PER, PSTRIDE = UPC / PER, LA = NS - 1;
+    const int q = L % UPC;
     if (!ASYNC) {
-        if (L % UPC == 0) st.enter(L / UPC);
-        return unit_of<V>(st, 0, L % UPC);
+        if (q == 0) st.enter(L / UPC);
+        return unit_of<V>(st, 0, q);
     }
-    const bool has1 = L + 1 < T && (L + 1) / UPC == L / UPC;
-    const bool has2 = L + 2 < T && (L + 2) / UPC == L / UPC;
-    if (L % UPC == 0) {
-        st.enter(L / UPC);
-        st.issue(p.r[L % 3], L % UPC);
-        if (has1) st.issue(p.r[(L + 1) % 3], (L + 1) % UPC);
+    const int rem = min(T - 1 - L, UPC - 1 - q);      // later units of this segment in this chunk
+    if (q == 0) {
+        if (PG_SPREAD_DMA) st.enter_split(); else st.enter(L / UPC);
+        for (int k = 0; k < LA; ++k)
+            if (k <= rem) st.issue(p.r[(L + k) % NS], q + k);
     }
-    if (has2) st.issue(p.r[(L + 2) % 3], (L + 2) % UPC);
-    if (has2) lds_retire<2>(p.r[L % 3]);
-    else if (has1) lds_retire<1>(p.r[L % 3]);
-    else lds_retire<0>(p.r[L % 3]);
-    return __builtin_bit_cast(V, p.r[L % 3]);
+    if (LA <= rem) st.issue(p.r[(L + LA) % NS], q + LA);
+    if (PG_SPREAD_DMA) {
+        // refill piece i of the freed slot goes out at unit i*PSTRIDE+PG_DMA_PHASE of this
+        // chunk; a segment ending inside the chunk flushes the rest with its last unit
+        if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
+        if (L == T - 1)
+            for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
+    }
+    if (PG_EARLY_RETIRE) {
+        // The retire "writes" its register as far as hipcc knows, and a VALU write directly
+        // before an MFMA read costs an s_nop: retire unit L+1 here, one MFMA early, so only
+        // the first unit of a chunk pays it.
+        if (q == 0) lds_retire(p.r[L % NS], min(LA, rem));
+        if (rem >= 1) lds_retire(p.r[(L + 1) % NS], min(LA, rem) - 1);
+    } else {
+        lds_retire(p.r[L % NS], min(LA, rem));
+    }
+    return __builtin_bit_cast(V, p.r[L % NS]);
 }
 
+#ifndef PG_SETPRIO
+#define PG_SETPRIO 0
+#endif
 // one B fragment against NO out tiles; unit row uu of a k-major segment with T units
-template <typename V, int NO, int T, bool ASYNC>
-__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V>& p, Stream16& st, int uu, V b) {
+template <typename V, int NO, int T, bool ASYNC, int NS>
+__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, Stream16& st, int uu, V b) {
+    if (PG_SETPRIO) __builtin_amdgcn_s_setprio(PG_SETPRIO);
 #pragma unroll
-    for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC>(p, st, uu * NO + o), b, acc[o]);
+    for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, uu * NO + o), b, acc[o]);
+    if (PG_SETPRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
+// `skb` = this lane half's 12 bone rows, `cutb` its 12 cutoff distances: both are opaque
+// bases (see opaque_ptr) so that each joint is an immediate offset, not a live register.
 template <typename V>
-__device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, const float* slot,
-                                          const float* cut, float tau, float px, float py, float pz, int h) {
-    APipe<V> p;
+__device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, const float* skb,
+                                          const float* cutb, float tau, float px, float py, float pz) {
+    APipeX<V> p;
     constexpr int T = XU * NT;
 #pragma clang loop unroll(full)
     for (int sb = 0; sb < 3; ++sb) {
@@ -122,7 +174,7 @@ __device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, 
         for (int k = 0; k < 4; ++k) {
             const int jj = 4 * sb + k;
             float x[18];
-            joint_values<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz, tau, cut[JH * h + jj], x);
+            joint_values<true>(skb + jj * 12, px, py, pz, tau, cutb[jj], x);
             lo[2 * k] = x[16];
             lo[2 * k + 1] = x[17];
             mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k, Op<V>::cvt(x));
@@ -160,10 +212,10 @@ __device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool 
 }
 
 // acc += W[tile o] * fin over the HU hidden units; out-tile-major segment starting at cbase
-template <typename V, int T, bool ASYNC>
-__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V>& p, Stream16& st, int o, const V* fin) {
+template <typename V, int T, bool ASYNC, int NS>
+__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V, NS>& p, Stream16& st, int o, const V* fin) {
 #pragma unroll
-    for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(next_a<V, T, ASYNC>(p, st, o * HU + u), fin[u], acc);
+    for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, o * HU + u), fin[u], acc);
 }
 
 // fout = relu(W fin + b), out-tile-major segment starting at chunk cbase.
@@ -180,7 +232,7 @@ __device__ __forceinline__ void hidden_layer(const V* fin, V* fout, Stream16& st
         constexpr int T = HU * NT;
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
-            acc = Op<V>::mfma(next_a<V, T, true>(p, st, o * HU + u), fin[u], acc);
+            acc = Op<V>::mfma(next_a<V, T, true, PG_PIPE_H>(p, st, o * HU + u), fin[u], acc);
             if (u == 3 && o > 0) relu_pack<V>(prev, fout[2 * (o - 1)], fout[2 * (o - 1) + 1], true);
         }
         prev = acc;
@@ -211,7 +263,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
     float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, pt = lane & 31;
     Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
@@ -239,6 +291,13 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
         const float* slot = rtab + ((int)(gpc / a.S) - r0) * SLOT_FLOATS;
+        // Lane-dependent bases made opaque: left visible, hipcc materialises one address
+        // register per joint (base + h-dependent offset) and spills them; a scratch reload
+        // then waits vmcnt(0), i.e. drains the weight DMA that must stay in flight.
+        const float* skb = opaque_ptr(slot + SLOT_SKT + JH * h * 12);
+        const float* cutv = opaque_ptr(cut + JH * h);
+        const float* cutd = opaque_ptr(cut + J + JH * h);
+        const float* tab = opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
         const float zz = a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
         const float px = __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
@@ -251,7 +310,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             f32x16 acc[NT];
 #pragma unroll
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
-            x_segment<V>(acc, st, C_L0, slot, cut, a.tau_v, px, py, pz, h);
+            x_segment<V>(acc, st, C_L0, skb, cutv, a.tau_v, px, py, pz);
             if (a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
@@ -270,13 +329,13 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         PG_STAMP(3);
         {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
             f32x16 acc[NT];
-            APipe<V> p5;
+            APipeX<V> p5;
 #pragma unroll
             for (int o = 0; o < NT; ++o) {
                 acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
                 row_tile<V, HU * NT, PG_ASYNC_X>(acc[o], p5, st, o, fa);
             }
-            x_segment<V>(acc, st, C_L5X, slot, cut, a.tau_v, px, py, pz, h);
+            x_segment<V>(acc, st, C_L5X, skb, cutv, a.tau_v, px, py, pz);
 #pragma unroll
             for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fb[2 * o], fb[2 * o + 1], true);
         }
@@ -301,7 +360,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         V fg[HU / 2];
         {
             f32x16 acc[NTV];
-            APipe<V> pv, pd;
+            APipe<V> pv;
+            APipeX<V> pd;
             constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
@@ -311,9 +371,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             float wd[JH];
 #pragma unroll
             for (int jj = 0; jj < JH; ++jj)
-                wd[jj] = cutoff_weight<true>(joint_dist<true>(slot + SLOT_SKT + (JH * h + jj) * 12, px, py, pz),
-                                       a.tau_d, cut[J + JH * h + jj]);
-            const float* tab = slot + SLOT_DTAB + h * DSEQ;
+                wd[jj] = cutoff_weight<true>(joint_dist<true>(skb + jj * 12, px, py, pz), a.tau_d, cutd[jj]);
 #pragma clang loop unroll(full)
             for (int uu = 0; uu < DU; ++uu) {
                 const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
@@ -342,7 +400,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         {
             APipe<V> pr;
 #pragma unroll
-            for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(next_a<V, HU / 2, true>(pr, st, u), fg[u], acc);
+            for (int u = 0; u < HU / 2; ++u) acc = Op<V>::mfma(next_a<V, HU / 2, true, PG_PIPE_H>(pr, st, u), fg[u], acc);
         }
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(acc[0], acc[1], acc[2], sigma);
