@@ -179,9 +179,11 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
 
 /* Host-only (no GPU touched): pack one net's tensors (same 24-tensor order as
  * pg_load_weights) into the weight stream and bias table the kernels consume, for tests
- * of the packing / stream-program logic.  stream_out may be NULL to query the size. */
+ * of the packing / stream-program logic.  stream_out may be NULL to query the size.
+ * view_fact != 0 selects the stream of the factorised view layer the 16-bit kernels use
+ * when a ray has >= 64 samples. */
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors,
-                  int framecode_ch, int precision, uint8_t* stream_out, int64_t stream_cap,
+                  int framecode_ch, int precision, int view_fact, uint8_t* stream_out, int64_t stream_cap,
                   int64_t* stream_bytes, float* bias_out /* 78*32 floats or NULL */,
                   int32_t* chunk_bytes /* out: ring chunk size the library was built with */);
 

@@ -69,7 +69,7 @@ PROTOTYPES = {
                                      _FP, _FP, C.c_int, _FP]),
     "pg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "pg_debug_pack": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_void_p,
+    "pg_debug_pack": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                 C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]),
     "pg_query": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

@@ -16,7 +16,7 @@
 #include "pg_pack.h"
 
 extern "C" {
-int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
@@ -41,8 +41,8 @@ struct NetState {
     std::vector<std::vector<float>> host;      // 24 tensors, reference order (see header)
     std::vector<float> codes_host;             // [n_codes+1,16]
     int n_codes = 0;
-    uint8_t* d_stream[PG_PREC_COUNT] = {};
-    size_t stream_bytes[PG_PREC_COUNT] = {};
+    uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
+    size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
     float* d_codes = nullptr;
 };
@@ -113,17 +113,24 @@ pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     return t;
 }
 
-int ensure_stream(pg_handle* h, int which, int prec) {
+// The 16-bit kernels factorise the view layer over rays when a pass cannot touch more than
+// MAXR_F rays (pg_layout.h); POSEGEN_VIEW_FACT=0 forces the direct form (A/B, debugging).
+bool use_fact(int prec, int S) {
+    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_VIEW_FACT"); return !(e && e[0] == '0'); }();
+    return allowed && is_shape_a(prec) && S >= FACT_MIN_S;
+}
+
+int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
-    if (ns.d_stream[prec]) return PG_OK;
+    if (ns.d_stream[prec][fact]) return PG_OK;
     std::vector<uint8_t> packed;
-    const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, packed);
+    const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, fact, packed);
     if (rc != 0) return fail(h, PG_EINVAL, "weight stream packing failed (%d) for precision %d", rc, prec);
     PG_HIP(h, hipSetDevice(h->device));
-    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec]), packed.size()));
-    PG_HIP(h, hipMemcpy(ns.d_stream[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
-    ns.stream_bytes[prec] = packed.size();
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec][fact]), packed.size()));
+    PG_HIP(h, hipMemcpy(ns.d_stream[prec][fact], packed.data(), packed.size(), hipMemcpyHostToDevice));
+    ns.stream_bytes[prec][fact] = packed.size();
     return PG_OK;
 }
 
@@ -149,7 +156,8 @@ int check_ready(pg_handle* h, bool need_fine) {
 int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
                 const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0) {
     const int prec = h->cfg.precision;
-    int rc = ensure_stream(h, which, prec);
+    const bool fact = use_fact(prec, S);
+    int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
@@ -157,7 +165,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = ns.d_stream[prec];
+    a.wstream = ns.d_stream[prec][fact];
     a.bias = ns.d_bias;
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
@@ -187,7 +195,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         PG_HIP(h, get(e1));
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
-    int e = sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
+    int e = sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
         PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
@@ -249,7 +257,7 @@ void pg_destroy(pg_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (NetState& ns : h->net) {
-        for (auto& p : ns.d_stream) if (p) (void)hipFree(p);
+        for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
     }
@@ -286,12 +294,13 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     ns.loaded = true;
     PG_HIP(h, hipSetDevice(h->device));
     for (int p = 0; p < PG_PREC_COUNT; ++p)
-        if (ns.d_stream[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p])); ns.d_stream[p] = nullptr; }
+        for (int f = 0; f < 2; ++f)
+            if (ns.d_stream[p][f]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p][f])); ns.d_stream[p][f] = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
-    return ensure_stream(h, which, h->cfg.precision);
+    return ensure_stream(h, which, h->cfg.precision, use_fact(h->cfg.precision, FACT_MIN_S));
 }
 
 int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau) {
@@ -333,7 +342,7 @@ int pg_set_precision(pg_handle* h, int precision) {
         return fail(h, PG_EINVAL, "pg_set_precision: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", precision);
     h->cfg.precision = precision;
     for (int w = 0; w < 2; ++w)
-        if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision); if (rc) return rc; }
+        if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision, use_fact(precision, FACT_MIN_S)); if (rc) return rc; }
     return PG_OK;
 }
 
@@ -371,7 +380,7 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
 }
 
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
-                  int precision, uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes, float* bias_out,
+                  int precision, int view_fact, uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes, float* bias_out,
                   int32_t* chunk_bytes) {
     if (!tensors || !shapes || n_tensors != 24) return fail(nullptr, PG_EINVAL, "pg_debug_pack: need 24 tensors");
     if (precision < 0 || precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_debug_pack: bad precision");
@@ -381,7 +390,7 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     pg_config cfg{};
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> packed;
-    const int rc = pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, packed);
+    const int rc = pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed);
     if (rc != 0) return fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;

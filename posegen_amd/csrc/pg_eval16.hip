@@ -58,7 +58,9 @@ template <> struct Op<f16x8> {
 #ifndef PG_DMA_WAVES
 #define PG_DMA_WAVES 8
 #endif
-using Stream16 = Stream<NWAVE, NCHUNK, PG_DMA_WAVES>;
+// FACT selects the factorised view layer (pg_layout.h) and with it the stream program
+template <bool FACT, bool FC>
+using StreamOf = Stream<NWAVE, (FACT ? pgp::AF::NCHUNK(FC) : NCHUNK), PG_DMA_WAVES>;
 static_assert(PG_DMA_WAVES == NWAVE || PG_SPREAD_DMA, "the bulk enter() waits vmcnt on every wave");
 
 __device__ __forceinline__ const float* opaque_ptr(const float* p) {
@@ -75,8 +77,8 @@ __device__ __forceinline__ const float* opaque_ptr(const float* p) {
 #define PG_ASYNC_VD true      // ... in the view-direction segment
 #endif
 
-template <typename V>
-__device__ __forceinline__ V unit_of(Stream16& st, int c, int pos) {
+template <typename V, typename ST>
+__device__ __forceinline__ V unit_of(ST& st, int c, int pos) {
     return __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(c, pos * UNIT_BYTES)));
 }
 
@@ -113,9 +115,9 @@ __device__ __forceinline__ void lds_retire(a128& r, int younger) {
 
 // A fragment of unit L (compile-time after unrolling) of a segment with T units: NS register
 // sets, reads issued NS-1 units ahead.  ASYNC = false: a plain (compiler-scheduled) read.
-template <typename V, int T, bool ASYNC, int NS>
-__device__ __forceinline__ V next_a(APipe<V, NS>& p, Stream16& st, int L) {
-    constexpr int PER = Stream16::PER, PSTRIDE = UPC / PER, LA = NS - 1;
+template <typename V, int T, bool ASYNC, int NS, typename ST>
+__device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
+    constexpr int PER = ST::PER, PSTRIDE = UPC / PER, LA = NS - 1;
     const int q = L % UPC;
     if (!ASYNC) {
         if (q == 0) st.enter(L / UPC);
@@ -151,8 +153,8 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, Stream16& st, int L) {
 #define PG_SETPRIO 0
 #endif
 // one B fragment against NO out tiles; unit row uu of a k-major segment with T units
-template <typename V, int NO, int T, bool ASYNC, int NS>
-__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, Stream16& st, int uu, V b) {
+template <typename V, int NO, int T, bool ASYNC, int NS, typename ST>
+__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, ST& st, int uu, V b) {
     if (PG_SETPRIO) __builtin_amdgcn_s_setprio(PG_SETPRIO);
 #pragma unroll
     for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, uu * NO + o), b, acc[o]);
@@ -162,8 +164,8 @@ __device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, Stream16& 
 // acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
 // `skb` = this lane half's 12 bone rows, `cutb` its 12 cutoff distances: both are opaque
 // bases (see opaque_ptr) so that each joint is an immediate offset, not a live register.
-template <typename V>
-__device__ __forceinline__ void x_segment(f32x16* acc, Stream16& st, int cbase, const float* skb,
+template <typename V, typename ST>
+__device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const float* skb,
                                           const float* cutb, float tau, float px, float py, float pz) {
     APipeX<V> p;
     constexpr int T = XU * NT;
@@ -212,8 +214,8 @@ __device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool 
 }
 
 // acc += W[tile o] * fin over the HU hidden units; out-tile-major segment starting at cbase
-template <typename V, int T, bool ASYNC, int NS>
-__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V, NS>& p, Stream16& st, int o, const V* fin) {
+template <typename V, int T, bool ASYNC, int NS, typename ST>
+__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V, NS>& p, ST& st, int o, const V* fin) {
 #pragma unroll
     for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, o * HU + u), fin[u], acc);
 }
@@ -221,8 +223,8 @@ __device__ __forceinline__ void row_tile(f32x16& acc, APipe<V, NS>& p, Stream16&
 // fout = relu(W fin + b), out-tile-major segment starting at chunk cbase.
 // The ReLU + 16-bit packing of tile o-1 (VALU, needs that tile's last MFMA to retire) is placed
 // after the first MFMAs of tile o, so it runs under them instead of draining the MFMA pipe.
-template <typename V>
-__device__ __forceinline__ void hidden_layer(const V* fin, V* fout, Stream16& st, int cbase,
+template <typename V, typename ST>
+__device__ __forceinline__ void hidden_layer(const V* fin, V* fout, ST& st, int cbase,
                                              const float* bias, int tile0, int h) {
     APipe<V> p;
     f32x16 prev;
@@ -251,21 +253,171 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
     }
 }
 
+
+// ===================== factorised view layer (pg_layout.h) ===============================
+constexpr int LDS_TOTAL_F = LDS_RTAB + MAXR_F * SLOTF_BYTES;
+static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view layer)");
+
+// per-ray slots: bone rows, o, d
+template <int NTHREADS>
+__device__ __forceinline__ void ray_tablef_phase1(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < nr * 288; idx += NTHREADS) {
+        const int rr = idx / 288, k = idx - rr * 288;
+        const int j = k / 12, e = k - j * 12;
+        reinterpret_cast<float*>(rt + rr * SLOTF_BYTES + SLOTF_SKT)[k] =
+            a.skts[(long long)(r0 + rr) * a.pose_stride + j * 16 + e];
+    }
+    for (int idx = tid; idx < nr * 6; idx += NTHREADS) {
+        const int rr = idx / 6, k = idx - rr * 6;
+        reinterpret_cast<float*>(rt + rr * SLOTF_BYTES + SLOTF_OD)[k] = a.rays[(long long)(r0 + rr) * 11 + k];
+    }
+}
+
+// T16[ray][j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(R_j d),
+// rows e, sin e, cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:25-37,
+// 172-193) as 16-bit MFMA operands, zero padded to 32; joint JC = the ray's frame code.
+template <typename V, bool FC, int NTHREADS>
+__device__ __forceinline__ void ray_tablef_phase2(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
+    constexpr int NJ = J + (FC ? 1 : 0);
+    for (int idx = threadIdx.x; idx < nr * NJ; idx += NTHREADS) {
+        const int rr = idx / NJ, j = idx - rr * NJ;
+        uint8_t* slot = rt + rr * SLOTF_BYTES;
+        float t[TK];
+#pragma unroll
+        for (int k = 0; k < TK; ++k) t[k] = 0.0f;
+        if (j < J) {
+            const float* sk = reinterpret_cast<const float*>(slot + SLOTF_SKT) + j * 12;
+            const float* od = reinterpret_cast<const float*>(slot + SLOTF_OD);
+            const float dx = od[3], dy = od[4], dz = od[5];
+            float e[3];
+            e[0] = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
+            e[1] = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
+            e[2] = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
+            const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float ev = e[c] * inv;
+                const float rev = ev * 0.15915494309189535f;
+                float sn = __builtin_amdgcn_sinf(rev), co = __builtin_amdgcn_cosf(rev);
+                t[c * ROWS_D] = ev;
+#pragma unroll
+                for (int f = 0; f < LD; ++f) {
+                    t[c * ROWS_D + 1 + 2 * f] = sn;
+                    t[c * ROWS_D + 2 + 2 * f] = co;
+                    const float s2 = 2.0f * sn * co;
+                    co = (co - sn) * (co + sn);
+                    sn = s2;
+                }
+            }
+        } else {
+            const float cf = a.cams ? a.cams[r0 + rr] : -1.0f;
+            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
+#pragma unroll
+            for (int k = 0; k < FC_CH; ++k) t[k] = a.codes[ci * FC_CH + k];
+        }
+        V* dst = reinterpret_cast<V*>(slot + SLOTF_T16 + j * (TK * 2));
+#pragma unroll
+        for (int q = 0; q < TK / 8; ++q) dst[q] = Op<V>::cvt(t + 8 * q);
+    }
+}
+
+// Y stage: Y[ray][j][o] for the rays of this pass.  Wave w: out tile w&3, the 12 (13 with the
+// frame code) joints of half w>>2; per joint two K=16 MFMAs with A = T16 (rows = rays) and
+// B = the wave's weight units of the current chunk (pg_pack.cpp).  C has the out channel on
+// the lane and rays 0..3 (lanes < 32) / 4..7 in registers 0..3: eight joints' worth of one
+// ray make the 16 bytes lane (h, o) of the second stage's A fragment (tile, u) holds.
+template <typename V, bool FC, typename ST>
+__device__ __forceinline__ void y_stage(ST& st, uint8_t* rt, int nr, int wave, int lane) {
+    constexpr int NE = JH + (FC ? 1 : 0);
+    constexpr int NCH = pgp::AF::CH_VY(FC);
+    const int t = wave & 3, hw = wave >> 2, hl = lane >> 5, col = lane & 31;
+    const uint8_t* trow = rt + min(col, nr - 1) * SLOTF_BYTES + SLOTF_T16 + hl * 16;
+    const uint8_t* trow_h = trow + hw * (JH * TK * 2);
+    uint8_t* ybase = rt + SLOTF_Y + ((t * 2) * 64 + 32 * hw + col) * 16 + 4 * hl * SLOTF_BYTES;
+    float yv[4][8];
+    f32x16 acc;
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NCH; ++c) {
+        st.enter_split();
+#pragma unroll
+        for (int i = 0; i < ST::PER; ++i) st.piece(i);
+#pragma clang loop unroll(full)
+        for (int i = 0; i < VY_UPW; ++i) {
+            const int n = c * VY_UPW + i, e = n / 2, ku = n % 2;
+            if (e >= NE) continue;
+            const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
+            const V av = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj + ku * 32));
+            const V bv = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(0, (wave * VY_UPW + i) * UNIT_BYTES)));
+            if (ku == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            }
+            acc = Op<V>::mfma(av, bv, acc);
+            if (ku == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r][e % 8] = acc[r];
+                if (e == 7 || e == NE - 1) {
+                    const int u = e / 8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int ee = (e % 8) + 1; ee < 8; ++ee) yv[r][ee] = 0.0f;
+                        // ray = r + 4 hl; only MAXR_F = 5 slots exist
+                        if (hl == 0 || r == 0)
+                            *reinterpret_cast<V*>(ybase + r * SLOTF_BYTES + u * 1024) = Op<V>::cvt(yv[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// second stage: acc[t] += sum_j w_j Y[ray][j][32t..] for the (at most two) rays of the wave
+template <typename V, bool FC>
+__device__ __forceinline__ void y_apply(f32x16* acc, const uint8_t* rt, const float* wd, int myr, int lane) {
+    const int h = lane >> 5;
+    float wx[16];
+#pragma unroll
+    for (int e = 0; e < JH; ++e) wx[e] = wd[e];
+    wx[12] = (FC && h == 0) ? 1.0f : 0.0f;
+    wx[13] = wx[14] = wx[15] = 0.0f;
+    const u32x4 w0 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx));
+    const u32x4 w1 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx + 8));
+    const int ra = __builtin_amdgcn_readfirstlane(myr);
+    const int rb = __builtin_amdgcn_readlane(myr, 63);
+    for (int ray = ra; ray <= rb; ++ray) {
+        const bool mine = myr == ray;
+        u32x4 b0, b1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { b0[q] = mine ? w0[q] : 0u; b1[q] = mine ? w1[q] : 0u; }
+        const uint8_t* yb = rt + ray * SLOTF_BYTES + SLOTF_Y + lane * 16;
+#pragma unroll
+        for (int t = 0; t < NTV; ++t) {
+            const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2) * 1024));
+            const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2 + 1) * 1024));
+            acc[t] = Op<V>::mfma(a0, __builtin_bit_cast(V, b0), acc[t]);
+            acc[t] = Op<V>::mfma(a1, __builtin_bit_cast(V, b1), acc[t]);
+        }
+    }
+}
+
 #if defined(PG_STAMPS)
 #define PG_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; } while (0)
 #else
 #define PG_STAMP(k) do {} while (0)
 #endif
 
-template <typename V, bool FC>
+template <typename V, bool FC, bool FACT>
 __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
     float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
+    uint8_t* rtf = smem + LDS_RTAB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, pt = lane & 31;
-    Stream16 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+    StreamOf<FACT, FC> st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
@@ -282,27 +434,37 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
         lds_barrier();                          // previous pass is done with the table
-        ray_table_phase1<NTHR>(a, rtab, r0, nr);
-        lds_barrier();
-        ray_table_phase2<NTHR, true>(rtab, nr);
-        lds_barrier();
+        if (FACT) {
+            ray_tablef_phase1<NTHR>(a, rtf, r0, nr);
+            lds_barrier();
+            ray_tablef_phase2<V, FC, NTHR>(a, rtf, r0, nr);
+            lds_barrier();
+            y_stage<V, FC>(st, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
+        } else {
+            ray_table_phase1<NTHR>(a, rtab, r0, nr);
+            lds_barrier();
+            ray_table_phase2<NTHR, true>(rtab, nr);
+            lds_barrier();
+        }
 
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
-        const float* slot = rtab + ((int)(gpc / a.S) - r0) * SLOT_FLOATS;
+        const int myr = (int)(gpc / a.S) - r0;
+        const float* slot = FACT ? reinterpret_cast<const float*>(rtf + myr * SLOTF_BYTES) : rtab + myr * SLOT_FLOATS;
+        const float* od = slot + (FACT ? SLOTF_OD / 4 : SLOT_O);
         // Lane-dependent bases made opaque: left visible, hipcc materialises one address
         // register per joint (base + h-dependent offset) and spills them; a scratch reload
         // then waits vmcnt(0), i.e. drains the weight DMA that must stay in flight.
         const float* skb = opaque_ptr(slot + SLOT_SKT + JH * h * 12);
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
-        const float* tab = opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
+        const float* tab = FACT ? nullptr : opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
         const float zz = a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
-        const float px = __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
-        const float py = __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
-        const float pz = __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
+        const float px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
+        const float py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
+        const float pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
 
         PG_STAMP(1);
         V fa[HU], fb[HU];
@@ -361,8 +523,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         {
             f32x16 acc[NTV];
             APipe<V> pv;
-            APipeX<V> pd;
-            constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
+            [[maybe_unused]] APipeX<V> pd;
+            [[maybe_unused]] constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
                 acc[o] = load_bias(bias, BT_VIEW + o, h);
@@ -372,23 +534,27 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
 #pragma unroll
             for (int jj = 0; jj < JH; ++jj)
                 wd[jj] = cutoff_weight<true>(joint_dist<true>(skb + jj * 12, px, py, pz), a.tau_d, cutd[jj]);
-#pragma clang loop unroll(full)
-            for (int uu = 0; uu < DU; ++uu) {
-                const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
-                const float4 t1 = *reinterpret_cast<const float4*>(tab + uu * 8 + 4);
-                float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = uu < JH * 3 ? uu / 3 : (8 * (uu - JH * 3) + e) / 3;
-                    x[e] = k < JH ? x[e] * wd[k] : 0.0f;
+            if (FACT) {
+                y_apply<V, FC>(acc, rtf, wd, myr, lane);
+            } else {
+    #pragma clang loop unroll(full)
+                for (int uu = 0; uu < DU; ++uu) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
+                    const float4 t1 = *reinterpret_cast<const float4*>(tab + uu * 8 + 4);
+                    float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = uu < JH * 3 ? uu / 3 : (8 * (uu - JH * 3) + e) / 3;
+                        x[e] = k < JH ? x[e] * wd[k] : 0.0f;
+                    }
+                    mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, uu, Op<V>::cvt(x));
                 }
-                mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, uu, Op<V>::cvt(x));
-            }
-            if (FC) {
-                const float4 t0 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h);
-                const float4 t1 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h + 4);
-                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, DU, Op<V>::cvt(x));
+                if (FC) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h);
+                    const float4 t1 = *reinterpret_cast<const float4*>(slot + SLOT_CODE + 8 * h + 4);
+                    const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    mma_row<V, NTV, TVD, PG_ASYNC_VD>(acc, pd, st, DU, Op<V>::cvt(x));
+                }
             }
 #pragma unroll
             for (int o = 0; o < NTV; ++o) relu_pack<V>(acc[o], fg[2 * o], fg[2 * o + 1], true);
@@ -417,29 +583,35 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC>
+template <typename V, bool FC, bool FACT>
 static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16_kernel<V, FC>;
+    auto k = eval16_kernel<V, FC, FACT>;
+    constexpr int LDS = FACT ? LDS_TOTAL_F : LDS_TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS, stream, a);
     return hipGetLastError();
 }
 
 }  // namespace pgd
 
-extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream) {
+template <typename V>
+static hipError_t dispatch_eval16(const pgd::EvalArgs& a, int framecode, int fact, int grid, hipStream_t s) {
     using namespace pgd;
+    if (fact) return framecode ? launch_eval16<V, true, true>(a, grid, s) : launch_eval16<V, false, true>(a, grid, s);
+    return framecode ? launch_eval16<V, true, false>(a, grid, s) : launch_eval16<V, false, false>(a, grid, s);
+}
+
+// fact = 1: factorised view layer (needs S >= pgl::FACT_MIN_S and the AF weight stream)
+extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e;
-    if (fp16) e = framecode ? launch_eval16<f16x8, true>(*a, grid, s) : launch_eval16<f16x8, false>(*a, grid, s);
-    else      e = framecode ? launch_eval16<bf16x8, true>(*a, grid, s) : launch_eval16<bf16x8, false>(*a, grid, s);
-    return (int)e;
+    return (int)(fp16 ? dispatch_eval16<pgd::f16x8>(*a, framecode, fact, grid, s)
+                      : dispatch_eval16<pgd::bf16x8>(*a, framecode, fact, grid, s));
 }
 
 extern "C" int pg_eval16_points_per_pass(void) { return pgd::PTS; }

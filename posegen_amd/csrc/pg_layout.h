@@ -104,6 +104,42 @@ constexpr int SLOT_FLOATS = 976;              // multiple of 4
 #endif
 constexpr int MAXR = PG_MAXR;                 // rays overlapped by one workgroup pass
 
+// ---- factorised view layer (16-bit kernels, >= 64 samples per ray) ---------------------
+// The 648 view inputs of a point are w_j(point) * T[ray][j][k]: 27 values k = c*9 + row per
+// joint that depend on the RAY only, times the per-point cutoff weight.  So
+//     W_vd xd = sum_j w_j(point) Y[ray][j][:],   Y[ray][j][o] = sum_k W_vd[o,(j,k)] T[ray][j][k]
+// Y is computed once per workgroup pass for the <= MAXR_F rays it touches ("Y stage": wave w
+// does out tile w&3 for the 12 joints of half w>>2, 2 MFMAs per joint with the rays as rows),
+// then every wave contracts over the joints of its points' ray(s) with two K=16 MFMAs per out
+// tile.  The frame code rides along as pseudo joint JC with weight 1.  Exact in real
+// arithmetic; 164 MFMAs and ~500 VALU ops per 32 points become ~40 and ~60.
+constexpr int TK = 32;                  // k padded per joint (27 used; frame code 16)
+constexpr int JC = J;                   // pseudo joint carrying the frame code
+constexpr int MAXR_F = 5;               // rays overlapped by one pass when S >= 64
+constexpr int FACT_MIN_S = 64;
+constexpr int SLOTF_SKT = 0;            // bytes: 24 x 12 floats
+constexpr int SLOTF_OD = 1152;          // o, d (6 floats), pad to 32 B
+constexpr int SLOTF_T16 = 1184;         // 25 joints x TK 16-bit values
+constexpr int SLOTF_Y = SLOTF_T16 + (J + 1) * TK * 2;   // 2784: [tile 4][u 2][64 lanes] x 16 B
+constexpr int SLOTF_BYTES = SLOTF_Y + 4 * 2 * 1024;     // 10976
+static_assert(SLOTF_T16 % 16 == 0 && SLOTF_Y % 16 == 0 && SLOTF_BYTES % 16 == 0, "LDS alignment");
+constexpr int VY_UPW = 4;               // stream units per wave per 32-unit chunk in the Y stage
+// view-input column (0 .. 647 + 16) multiplied by value k of joint j; -1 = zero pad
+PG_HD constexpr int vd_channel(int j, int k) {
+    if (j < J) return k < 3 * ROWS_D ? (k % ROWS_D) * (3 * J) + 3 * j + k / ROWS_D : -1;
+    return k < FC_CH ? CH_D + k : -1;
+}
+// joint the Y-stage wave w (half w>>2) handles as its e-th (0..12); -1 = none
+PG_HD constexpr int vy_joint(int w, int e, bool fc) {
+    return e < JH ? JH * (w >> 2) + e : ((fc && (w >> 2) == 0 && e == JH) ? JC : -1);
+}
+// joint in slot e of k-unit u for lane half h in the second stage; -1 = zero
+PG_HD constexpr int vy_slot_joint(int u, int h, int e, bool fc) {
+    if (u == 0) return JH * h + e;
+    if (e < 4) return JH * h + 8 + e;
+    return (fc && h == 0 && e == 4) ? JC : -1;
+}
+
 // bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1)
 constexpr int BT_LAYER0 = 0;
 constexpr int BT_FEAT = 64;

@@ -72,7 +72,7 @@ float NetTensors::w(int mat, int row, int col) const {
     return p[(size_t)row * cols + col];
 }
 
-static std::vector<Segment> program(int shape, bool fc) {
+static std::vector<Segment> program(int shape, bool fc, bool fact) {
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
     const bool km = (shape == SHAPE_B);
@@ -88,7 +88,7 @@ static std::vector<Segment> program(int shape, bool fc) {
         s.push_back({MAT_ALPHA, 1, true, {hid(0)}});
     }
     s.push_back({MAT_VIEW, NTV, km, {hid(0)}});
-    {
+    if (!fact) {
         Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
         if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
         s.push_back(v);
@@ -97,18 +97,42 @@ static std::vector<Segment> program(int shape, bool fc) {
     return s;
 }
 
-int pack_stream(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& out,
+int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base) {
     const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A : SHAPE_B;
     const bool is_f32 = precision == PG_PREC_FP32;
     const bool is_bf = precision == PG_PREC_BF16 || precision == PG_PREC_BF16X3;
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3;
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
+    if (fact && shape != SHAPE_A) return -3;
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
     if (seg_chunk_base) seg_chunk_base->clear();
-    for (const Segment& sg : program(shape, fc)) {
+    auto put16 = [&](size_t at, float wv) {
+        const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
+        std::memcpy(&out[at], &hi, 2);
+    };
+    if (fact) {
+        // Y stage: chunk c holds, for every wave w, its units 4c..4c+3 at positions 4w..4w+3.
+        // Unit n of wave w = (joint e = n/2, k-unit ku = n%2) of out tile w&3 as a B operand:
+        // lane (hl, col) = out channel 32(w&3)+col, values k = 16ku + 8hl + 0..7 of that joint.
+        if (seg_chunk_base) seg_chunk_base->push_back(0);
+        for (int c = 0; c < AF::CH_VY(fc); ++c)
+            for (int w = 0; w < 8; ++w)
+                for (int i = 0; i < VY_UPW; ++i) {
+                    const int n = c * VY_UPW + i, j = vy_joint(w, n / 2, fc), ku = n % 2;
+                    const size_t base = out.size();
+                    out.resize(base + 1024, 0);
+                    if (j < 0) continue;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ch = vd_channel(j, 16 * ku + 8 * (lane >> 5) + e);
+                            if (ch >= 0) put16(base + lane * 16 + e * 2, t.w(MAT_VIEW, 32 * (w & 3) + (lane & 31), W + ch));
+                        }
+                }
+    }
+    for (const Segment& sg : program(shape, fc, fact)) {
         if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
         // flatten the input units of this segment
         struct U { int seq, u, colbase; };
@@ -143,7 +167,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, std::vector<uint8_t
         }
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    const size_t nchunk = shape == SHAPE_A ? A::NCHUNK : B::NCHUNK;
+    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK(fc) : A::NCHUNK) : B::NCHUNK;
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
 }

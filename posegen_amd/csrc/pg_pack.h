@@ -25,7 +25,8 @@ struct NetTensors {
 };
 
 // Packs the weight stream for `precision`; returns 0, or <0 on an internal layout error.
-int pack_stream(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out,
+// `fact` selects the factorised-view program of the 16-bit kernels (pg_program.h AF).
+int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base = nullptr);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
 

@@ -48,6 +48,20 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 }
 }  // namespace A
 
+// ---------------- shape A with the factorised view layer (pg_layout.h) ---------------
+// [Y stage][L0][L1..4][L5h][L5x][L6][L7][feature+alpha][view <- feature][rgb]
+namespace AF {
+static_assert(A::UPC == 8 * VY_UPW, "Y stage: 8 waves x VY_UPW units per chunk");
+constexpr int CH_VY(bool fc) { return cdiv(2 * (JH + (fc ? 1 : 0)), VY_UPW); }     // 6 / 7
+constexpr int NCHUNK(bool fc) {
+    return CH_VY(fc) + 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_FA + A::CH_VF + 1;
+}
+// MFMAs per 32-point group: the trunk as in A, 2*(12|13) Y-stage + 8 or 16 second-stage ones
+constexpr int MFMA_PER_GROUP(bool fc) {
+    return A::MFMA_PER_GROUP(false) - A::DU * NTV + 2 * (JH + (fc ? 1 : 0)) + 8;
+}
+}  // namespace AF
+
 // ---------------- shape B: fp32 (UE 4, 1-KiB units) or split 16-bit (UE 8, 2-KiB) ---
 // bytes per sequence position per out tile are the same for both (256 B), so are the chunk counts
 namespace B {

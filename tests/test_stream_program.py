@@ -48,7 +48,7 @@ def hseq_channel(i, h):
     return 32 * (i // 16) + rho(i % 16, h)
 
 
-def pack(weights, cfg, prec):
+def pack(weights, cfg, prec, fact=False):
     lib = _ffi.load_library()
     arrs = [np.ascontiguousarray(weights[k], dtype=np.float32) for k in NET_TENSOR_ORDER]
     ptrs = (C.c_void_p * 24)(*[a.ctypes.data for a in arrs])
@@ -56,11 +56,11 @@ def pack(weights, cfg, prec):
     for i, a in enumerate(arrs):
         shp[2 * i], shp[2 * i + 1] = a.shape[0], (a.shape[1] if a.ndim == 2 else 1)
     size, chunk = C.c_int64(), C.c_int32()
-    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(size), None, C.byref(chunk))
+    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), None, 0, C.byref(size), None, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
     buf = np.zeros(size.value, dtype=np.uint8)
     bias = np.zeros(78 * 32, dtype=np.float32)
-    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, buf.ctypes.data, size.value, C.byref(size),
+    rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
     return buf, bias, chunk.value
@@ -105,9 +105,54 @@ def q16(x, prec):
     return x
 
 
-def emulate(stream, bias, chunk_bytes, prec, x, cfg):
-    """x: [32 pts, 1080(+code16)] oracle input rows -> raw [32, 4] through the packed stream."""
+def vd_channel(j, k):
+    if j < J:
+        return (k % 9) * 72 + 3 * j + k // 9 if k < 27 else -1
+    return 648 + k if k < 16 else -1
+
+
+def vy_joint(w, e, fc):
+    return JH * (w >> 2) + e if e < JH else (J if fc and (w >> 2) == 0 and e == JH else -1)
+
+
+def vy_slot_joint(u, h, e, fc):
+    if u == 0:
+        return JH * h + e
+    if e < 4:
+        return JH * h + 8 + e
+    return J if fc and h == 0 and e == 4 else -1
+
+
+def y_stage(wv, tray, fc, prec):
+    """Y[25, 128] of one ray from the leading Y-stage chunks (pg_pack.cpp, pg_eval16.hip y_stage):
+    wave w multiplies its units (chunk n//4, position 4w + n%4) as B operands (lane (hl, o):
+    k = 16ku + 8hl + e) with the ray's 16-bit view values T16[j][k]."""
+    ne = JH + (1 if fc else 0)
+    nch = -(-2 * ne // 4)
+    t16 = q16(tray.astype(np.float32), prec)
+    y = np.zeros((J + 1, VW), dtype=np.float32)
+    for w in range(8):
+        for n in range(2 * ne):
+            j, ku = vy_joint(w, n // 2, fc), n % 2
+            off = (n // 4) * wv.cb + (4 * w + n % 4) * 1024
+            unit = wv.s[off:off + 1024].reshape(64, 16)
+            vals = ((unit.view(np.uint16).astype(np.uint32) << 16).view(np.float32) if prec == PREC_BF16
+                    else unit.view(np.float16).astype(np.float32)).reshape(2, 32, 8)      # [hl, o, e]
+            if j < 0:
+                assert not vals.any()
+                continue
+            kk = t16[j, 16 * ku:16 * ku + 16].reshape(2, 8)
+            y[j, 32 * (w & 3):32 * (w & 3) + 32] += np.einsum("he,hoe->o", kk, vals)
+    wv.chunk = nch - 1
+    return q16(y, prec)
+
+
+def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
+    """x: [32 pts, 1080(+code16)] oracle input rows -> raw [32, 4] through the packed stream.
+    fact = (tray [25,32], wpt [32,24]): the factorised view layer with x[:,432:1080] = wpt (x) tray."""
     wv = Wave(stream, chunk_bytes, prec)
+    if fact is not None:
+        yq = y_stage(wv, fact[0], bool(cfg.framecode_ch), prec)
     shape_a = prec in (PREC_BF16, PREC_FP16)
     ue = wv.ue
 
@@ -167,10 +212,22 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg):
         sigma = segment(1, True, [(hv, HSEQ)], BT_ALPHA)[0][0]
     fv, _ = hidden_vals(feat, relu=False)
     vt = segment(NTV, km, [(fv, HSEQ)], BT_VIEW)
-    ins = [(seq_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
-    if cfg.framecode_ch:
-        ins.append((seq_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
-    vt = segment(NTV, True, ins, 0, acc=vt)
+    if fact is not None:
+        wq = q16(fact[1].astype(np.float32), prec)                  # [pt, 24]
+        for u in range(2):
+            for h in range(2):
+                for e in range(8):
+                    j = vy_slot_joint(u, h, e, bool(cfg.framecode_ch))
+                    if j < 0:
+                        continue
+                    wj = wq[:, j] if j < J else np.ones(32, dtype=np.float32)
+                    for o in range(NTV):
+                        vt[o] += np.outer(yq[j, 32 * o:32 * o + 32], wj)
+    else:
+        ins = [(seq_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
+        if cfg.framecode_ch:
+            ins.append((seq_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
+        vt = segment(NTV, True, ins, 0, acc=vt)
     gv, _ = hidden_vals(vt)
     rgb = segment(1, km, [(gv, VW // 2)], BT_RGB)[0]
     return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
@@ -178,27 +235,42 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg):
 
 @pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 2e-2), (PREC_FP16, "fp16", 4e-3)])
 @pytest.mark.parametrize("fc", [False, True])
-def test_packed_stream_reproduces_mlp(prec, quant, tol, fc):
+@pytest.mark.parametrize("fact", [False, True])
+def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
     try:
         _ffi.load_library()
     except _ffi.HipLibraryError as e:
         pytest.skip(str(e))
+    if fact and prec == PREC_FP32:
+        pytest.skip("the fp32 kernel keeps the direct view layer")
     cfg = h36m_config() if fc else surreal_config()
     w = syn.make_weights(cfg, 3)
-    stream, bias, chunk_bytes = pack(w, cfg, prec)
+    stream, bias, chunk_bytes = pack(w, cfg, prec, fact)
     rng = np.random.RandomState(0)
     x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
     x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)     # cutoff-weighted magnitudes
+    fact_in = None
+    if fact:      # one ray: view inputs = per-point joint weight x per-ray value
+        tray = np.zeros((J + 1, 32), dtype=np.float32)
+        tray[:J, :27] = rng.uniform(-1, 1, size=(J, 27))
+        wpt = rng.uniform(0, 1, size=(32, J)).astype(np.float32)
+        for j in range(J):
+            for k in range(27):
+                x[:, 432 + vd_channel(j, k)] = wpt[:, j] * tray[j, k]
+        fact_in = (tray, wpt)
     ocfg = oracle_cfg(cfg, 79.6, 79.6)
     ocfg.quant = quant
     tw = {k: torch.tensor(v) for k, v in w.items()}
     if fc:
         idx = rng.randint(0, cfg.n_framecodes, size=(32, 1)).astype(np.float32)
+        if fact:
+            idx[:] = idx[0]                                            # one ray, one frame code
+            fact_in[0][J, :16] = w["framecodes.codes.weight"][int(idx[0, 0])]
         ref = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1)), tw, ocfg).numpy()
         x_em = np.concatenate([x, w["framecodes.codes.weight"][idx[:, 0].astype(int)]], 1)
     else:
         ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
         x_em = x
-    raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg)
+    raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg, fact_in)
     assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
     np.testing.assert_allclose(raw, ref, rtol=0, atol=tol * max(1.0, float(np.abs(ref).max()) / 10))
