@@ -72,6 +72,7 @@ struct Stream {
     uint32_t fill_slot;    // ring slot that fetch goes to
     uint32_t rd_off;       // this lane's byte offset into the ring for the current chunk
     uint32_t ring_lds;     // LDS byte address of the ring (for asm ds_read)
+    uint32_t lane16;       // lane * 16
 
     __device__ __forceinline__ bool dma_wave() const { return NDMA == NWAVE || (wave >= dma_base() && wave < dma_base() + NDMA); }
     static constexpr int dma_base() { return NDMA == NWAVE ? 0 : PG_DMA_BASE; }
@@ -136,9 +137,14 @@ struct Stream {
                                                                                   : rd_off + CHUNK_BYTES;
         asm volatile("" : "+v"(rd_off)::"memory");
     }
+    // One refill piece, issued by asm in the SGPR-base + 32-bit lane offset form: through the
+    // builtin hipcc forms a 64-bit VGPR address (a v_lshl_add_u64) for every one of the ~224
+    // pieces per pass.  m0 (the LDS destination) is not otherwise used by these kernels.
     __device__ __forceinline__ void piece(int i) const {
+        if (!dma_wave()) return;
         const uint8_t* sbase = wstream + (cur_src + i * 1024);      // wave-uniform
-        if (dma_wave()) glds16(sbase + (uint32_t)(lane * 16), ring + cur_dst + i * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(ring_lds + cur_dst + i * 1024), "v"(lane16), "s"(sbase) : "memory");
     }
     __device__ __forceinline__ const uint8_t* at(int /*chunk*/, int byte_off) const {
         return ring + byte_off + rd_off;
@@ -218,17 +224,34 @@ __device__ __forceinline__ float cutoff_weight(float v, float tau, float c) {
     return 1.0f - 1.0f / (1.0f + expf(-t));
 }
 
+// FAST form with the constants folded on entry to the kernel: tl = tau log2(e), cs = -c tl
+__device__ __forceinline__ float cutoff_weight_fast(float v, float tl, float cs) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(v, tl, cs)));
+}
+
 // The 18 density-input values of one joint for one point (RelDist + VecNorm + cutoff
 // embedding, encoders.py:101-122,172-193; cutoff_embedder.py:111-174):
 //   x[0] = v w, x[1+2f] = sin(2^f v) w, x[2+2f] = cos(2^f v) w (f < 7), x[15..17] = q/|q|
 // sin/cos of the octaves by exact angle doubling from one sincos of v.
 template <bool FAST>
+__device__ __forceinline__ void joint_values_q(float qx, float qy, float qz, float tau, float cut, float* x);
+
+template <bool FAST>
 __device__ __forceinline__ void joint_values(const float* sk, float px, float py, float pz,
                                              float tau, float cut, float* x) {
     float qx, qy, qz;
     bone_local(sk, px, py, pz, qx, qy, qz);
-    const float v = pg_sqrt<FAST>(qx * qx + qy * qy + qz * qz);
-    const float w = cutoff_weight<FAST>(v, tau, cut);
+    joint_values_q<FAST>(qx, qy, qz, tau, cut, x);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void joint_values_q(float qx, float qy, float qz, float tau, float cut, float* x) {
+    const float d2 = qx * qx + qy * qy + qz * qz;
+    // FAST: `tau`/`cut` are the folded constants of cutoff_weight_fast; one v_rsq gives both
+    // |q| and 1/max(|q|, 1e-12)
+    const float rinv = FAST ? __builtin_amdgcn_rsqf(fmaxf(d2, 1e-24f)) : 0.0f;
+    const float v = FAST ? d2 * rinv : sqrtf(d2);
+    const float w = FAST ? cutoff_weight_fast(v, tau, cut) : cutoff_weight<false>(v, tau, cut);
     float s, c;
     if (FAST) {
         const float rev = v * 0.15915494309189535f;      // v_sin/v_cos take revolutions
@@ -238,17 +261,33 @@ __device__ __forceinline__ void joint_values(const float* sk, float px, float py
         sincosf(v, &s, &c);
     }
     x[0] = v * w;
-#pragma unroll
-    for (int f = 0; f < LV; ++f) {
-        x[1 + 2 * f] = s * w;
-        x[2 + 2 * f] = c * w;
-        const float s2 = 2.0f * s * c;
-        c = (c - s) * (c + s);
-        s = s2;
-    }
-    const float inv = pg_div<FAST>(1.0f, fmaxf(v, 1e-12f));
     if (FAST) {
-        x[15] = qx * inv; x[16] = qy * inv; x[17] = qz * inv;
+        // weighted doubling: S = w sin, C = w cos carried beside the plain pair, 5 ops per octave
+        //   sin 2a = (2 s) c,  cos 2a = 1 - (2 s) s,  w sin 2a = (2 s) C,  w cos 2a = w - (2 s) S
+        float S = s * w, C = c * w;
+#pragma unroll
+        for (int f = 0; f < LV; ++f) {
+            x[1 + 2 * f] = S;
+            x[2 + 2 * f] = C;
+            if (f + 1 < LV) {
+                const float t = s + s;
+                const float sn = t * c, cn = fmaf(-t, s, 1.0f);
+                const float Sn = t * C, Cn = fmaf(-t, S, w);
+                s = sn; c = cn; S = Sn; C = Cn;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < LV; ++f) {
+            x[1 + 2 * f] = s * w;
+            x[2 + 2 * f] = c * w;
+            const float s2 = 2.0f * s * c;
+            c = (c - s) * (c + s);
+            s = s2;
+        }
+    }
+    if (FAST) {
+        x[15] = qx * rinv; x[16] = qy * rinv; x[17] = qz * rinv;
     } else {
         const float den = fmaxf(v, 1e-12f);
         x[15] = qx / den; x[16] = qy / den; x[17] = qz / den;

@@ -164,9 +164,25 @@ __device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, ST& st, in
 // acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
 // `skb` = this lane half's 12 bone rows, `cutb` its 12 cutoff distances: both are opaque
 // bases (see opaque_ptr) so that each joint is an immediate offset, not a live register.
-template <typename V, typename ST>
-__device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const float* skb,
-                                          const float* cutb, float tau, float px, float py, float pz) {
+// bone-local position of the wave's point for joint jj of its lane half
+struct QFromRows {      // q = R p + t from the bone rows (classic table)
+    const float* skb; float px, py, pz;
+    __device__ __forceinline__ void operator()(int jj, float& qx, float& qy, float& qz) const {
+        bone_local(skb + jj * 12, px, py, pz, qx, qy, qz);
+    }
+};
+struct QFromAB {        // q = a + z b from the per-ray (a, b) table (pg_layout.h SLOTF_AB)
+    const float* ab; float z;
+    __device__ __forceinline__ void operator()(int jj, float& qx, float& qy, float& qz) const {
+        const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
+        qx = fmaf(z, hi.x, lo.x); qy = fmaf(z, hi.y, lo.y); qz = fmaf(z, hi.z, lo.z);
+    }
+};
+
+template <typename V, typename ST, typename Q>
+__device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const Q& qof,
+                                          const float* cutb, float tau) {
     APipeX<V> p;
     constexpr int T = XU * NT;
 #pragma clang loop unroll(full)
@@ -176,7 +192,9 @@ __device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const 
         for (int k = 0; k < 4; ++k) {
             const int jj = 4 * sb + k;
             float x[18];
-            joint_values<true>(skb + jj * 12, px, py, pz, tau, cutb[jj], x);
+            float qx, qy, qz;
+            qof(jj, qx, qy, qz);
+            joint_values_q<true>(qx, qy, qz, tau, cutb[jj], x);
             lo[2 * k] = x[16];
             lo[2 * k + 1] = x[17];
             mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k, Op<V>::cvt(x));
@@ -258,27 +276,13 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
 constexpr int LDS_TOTAL_F = LDS_RTAB + MAXR_F * SLOTF_BYTES;
 static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view layer)");
 
-// per-ray slots: bone rows, o, d
-template <int NTHREADS>
-__device__ __forceinline__ void ray_tablef_phase1(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < nr * 288; idx += NTHREADS) {
-        const int rr = idx / 288, k = idx - rr * 288;
-        const int j = k / 12, e = k - j * 12;
-        reinterpret_cast<float*>(rt + rr * SLOTF_BYTES + SLOTF_SKT)[k] =
-            a.skts[(long long)(r0 + rr) * a.pose_stride + j * 16 + e];
-    }
-    for (int idx = tid; idx < nr * 6; idx += NTHREADS) {
-        const int rr = idx / 6, k = idx - rr * 6;
-        reinterpret_cast<float*>(rt + rr * SLOTF_BYTES + SLOTF_OD)[k] = a.rays[(long long)(r0 + rr) * 11 + k];
-    }
-}
-
-// T16[ray][j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(R_j d),
-// rows e, sin e, cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:25-37,
-// 172-193) as 16-bit MFMA operands, zero padded to 32; joint JC = the ray's frame code.
+// Per-ray slots of the factorised path, one thread per (ray, joint):
+//   AB[j] = (a = R_j o + t_j, b = R_j d)                      (core/encoders.py:8-37)
+//   T16[j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(b), rows e, sin e,
+//   cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:172-193) as 16-bit MFMA
+//   operands, zero padded to 32; joint JC = the ray's frame code.
 template <typename V, bool FC, int NTHREADS>
-__device__ __forceinline__ void ray_tablef_phase2(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
+__device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
     constexpr int NJ = J + (FC ? 1 : 0);
     for (int idx = threadIdx.x; idx < nr * NJ; idx += NTHREADS) {
         const int rr = idx / NJ, j = idx - rr * NJ;
@@ -287,13 +291,19 @@ __device__ __forceinline__ void ray_tablef_phase2(const EvalArgs& a, uint8_t* rt
 #pragma unroll
         for (int k = 0; k < TK; ++k) t[k] = 0.0f;
         if (j < J) {
-            const float* sk = reinterpret_cast<const float*>(slot + SLOTF_SKT) + j * 12;
-            const float* od = reinterpret_cast<const float*>(slot + SLOTF_OD);
-            const float dx = od[3], dy = od[4], dz = od[5];
+            const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
+            const float4 ra = sk[0], rb = sk[1], rc = sk[2];
+            const float* ry = a.rays + (long long)(r0 + rr) * 11;
+            const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
             float e[3];
-            e[0] = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
-            e[1] = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
-            e[2] = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
+            e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
+            e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
+            e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
+            float4* ab = reinterpret_cast<float4*>(slot + SLOTF_AB + j * 32);
+            ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
+                                fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
+                                fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
+            ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
             const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -418,10 +428,12 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, pt = lane & 31;
     StreamOf<FACT, FC> st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
-               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
+               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING), (uint32_t)lane * 16u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
-    if (tid < 48) cut[tid] = a.cutoff[tid];
+    // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
+    const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
+    if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
     st.start();
 
 #if defined(PG_STAMPS)
@@ -435,9 +447,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const int nr = (int)(plast / a.S) - r0 + 1;
         lds_barrier();                          // previous pass is done with the table
         if (FACT) {
-            ray_tablef_phase1<NTHR>(a, rtf, r0, nr);
-            lds_barrier();
-            ray_tablef_phase2<V, FC, NTHR>(a, rtf, r0, nr);
+            ray_tablef<V, FC, NTHR>(a, rtf, r0, nr);
             lds_barrier();
             y_stage<V, FC>(st, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
         } else {
@@ -452,19 +462,24 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const long long gpc = valid ? gp : a.n_points - 1;
         const int myr = (int)(gpc / a.S) - r0;
         const float* slot = FACT ? reinterpret_cast<const float*>(rtf + myr * SLOTF_BYTES) : rtab + myr * SLOT_FLOATS;
-        const float* od = slot + (FACT ? SLOTF_OD / 4 : SLOT_O);
+        const float* od = slot + SLOT_O;      // classic table only
         // Lane-dependent bases made opaque: left visible, hipcc materialises one address
         // register per joint (base + h-dependent offset) and spills them; a scratch reload
         // then waits vmcnt(0), i.e. drains the weight DMA that must stay in flight.
-        const float* skb = opaque_ptr(slot + SLOT_SKT + JH * h * 12);
+        const float* skb = opaque_ptr(FACT ? slot + SLOTF_AB / 4 + JH * h * 8 : slot + SLOT_SKT + JH * h * 12);
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
         const float* tab = FACT ? nullptr : opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
         const float zz = a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
-        const float px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
-        const float py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
-        const float pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
+        float px = 0.0f, py = 0.0f, pz = 0.0f;
+        if (!FACT) {
+            px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
+            py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
+            pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
+        }
+        const QFromRows q_rows{skb, px, py, pz};
+        const QFromAB q_ab{skb, zz};
 
         PG_STAMP(1);
         V fa[HU], fb[HU];
@@ -472,7 +487,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             f32x16 acc[NT];
 #pragma unroll
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
-            x_segment<V>(acc, st, C_L0, skb, cutv, a.tau_v, px, py, pz);
+            if (FACT) x_segment<V>(acc, st, C_L0, q_ab, cutv, tlv);
+            else x_segment<V>(acc, st, C_L0, q_rows, cutv, tlv);
             if (a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
@@ -497,7 +513,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
                 acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
                 row_tile<V, HU * NT, PG_ASYNC_X>(acc[o], p5, st, o, fa);
             }
-            x_segment<V>(acc, st, C_L5X, skb, cutv, a.tau_v, px, py, pz);
+            if (FACT) x_segment<V>(acc, st, C_L5X, q_ab, cutv, tlv);
+            else x_segment<V>(acc, st, C_L5X, q_rows, cutv, tlv);
 #pragma unroll
             for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fb[2 * o], fb[2 * o + 1], true);
         }
@@ -533,7 +550,11 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             float wd[JH];
 #pragma unroll
             for (int jj = 0; jj < JH; ++jj)
-                wd[jj] = cutoff_weight<true>(joint_dist<true>(skb + jj * 12, px, py, pz), a.tau_d, cutd[jj]);
+            {
+                float qx, qy, qz;
+                if (FACT) q_ab(jj, qx, qy, qz); else q_rows(jj, qx, qy, qz);
+                wd[jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+            }
             if (FACT) {
                 y_apply<V, FC>(acc, rtf, wd, myr, lane);
             } else {

@@ -117,11 +117,12 @@ constexpr int TK = 32;                  // k padded per joint (27 used; frame co
 constexpr int JC = J;                   // pseudo joint carrying the frame code
 constexpr int MAXR_F = 5;               // rays overlapped by one pass when S >= 64
 constexpr int FACT_MIN_S = 64;
-constexpr int SLOTF_SKT = 0;            // bytes: 24 x 12 floats
-constexpr int SLOTF_OD = 1152;          // o, d (6 floats), pad to 32 B
-constexpr int SLOTF_T16 = 1184;         // 25 joints x TK 16-bit values
-constexpr int SLOTF_Y = SLOTF_T16 + (J + 1) * TK * 2;   // 2784: [tile 4][u 2][64 lanes] x 16 B
-constexpr int SLOTF_BYTES = SLOTF_Y + 4 * 2 * 1024;     // 10976
+// Per-ray slot (bytes).  AB: per joint a = R_j o + t_j and b = R_j d (8 floats, 2 pads), so that
+// the bone-local position of a sample is q = a + z b: 3 FMAs per joint instead of 9 + 3.
+constexpr int SLOTF_AB = 0;             // 24 x 8 floats
+constexpr int SLOTF_T16 = J * 32;       // 768: 25 joints x TK 16-bit values
+constexpr int SLOTF_Y = SLOTF_T16 + (J + 1) * TK * 2;   // 2368: [tile 4][u 2][64 lanes] x 16 B
+constexpr int SLOTF_BYTES = SLOTF_Y + 4 * 2 * 1024;     // 10560
 static_assert(SLOTF_T16 % 16 == 0 && SLOTF_Y % 16 == 0 && SLOTF_BYTES % 16 == 0, "LDS alignment");
 constexpr int VY_UPW = 4;               // stream units per wave per 32-unit chunk in the Y stage
 // view-input column (0 .. 647 + 16) multiplied by value k of joint j; -1 = zero pad

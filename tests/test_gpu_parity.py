@@ -106,8 +106,12 @@ def _oracle_stage(g, cfg, quant):
     return ocfg, torch_weights(wc), torch_weights(wf)
 
 
+# 16-bit modes are compared with the oracle emulating the operand rounding; the kernels form the
+# bone-local position as (R o + t) + z (R d) and factorise the view layer over rays, so a few
+# operands round the other way than in the oracle's direct form: the bound is ~1.5 operand ulps
+# of the largest |raw| (the error against the unrounded oracle is the same for both forms).
 @pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 4e-2),
-                                            (PREC_FP16, "fp16", 5e-3)]
+                                            (PREC_FP16, "fp16", 8e-3)]
                          + ([(PREC_BF16X3, None, 3e-3), (PREC_FP16X3, None, 1e-3)] if X3 else []))
 def test_stage_eval_coarse(casters, prec, quant, tol):
     """raw (rgb_raw, sigma_raw) and the layer-0 pre-activation of the coarse net."""
