@@ -184,7 +184,7 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
  * when a ray has >= 64 samples. */
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors,
                   int framecode_ch, int precision, int view_fact, uint8_t* stream_out, int64_t stream_cap,
-                  int64_t* stream_bytes, float* bias_out /* 78*32 floats or NULL */,
+                  int64_t* stream_bytes, float* bias_out /* 82*32 floats or NULL */,
                   int32_t* chunk_bytes /* out: ring chunk size the library was built with */);
 
 /* Static facts for the host: bytes of the packed weight stream of one net, and the

@@ -110,6 +110,7 @@ pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     t.view_w = ns.host[20].data();  t.view_b = ns.host[21].data();
     t.view_cols = W + CH_D + cfg.framecode_ch;
     t.rgb_w = ns.host[22].data();   t.rgb_b = ns.host[23].data();
+    t.fold();
     return t;
 }
 

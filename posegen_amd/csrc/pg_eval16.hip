@@ -149,6 +149,15 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
     return __builtin_bit_cast(V, p.r[L % NS]);
 }
 
+#ifndef PG_PIN_TILE
+#define PG_PIN_TILE 1
+#endif
+#ifndef PG_RELU_AT
+#define PG_RELU_AT 3
+#endif
+#ifndef PG_BIAS_AT
+#define PG_BIAS_AT 9
+#endif
 #ifndef PG_SETPRIO
 #define PG_SETPRIO 0
 #endif
@@ -245,16 +254,25 @@ template <typename V, typename ST>
 __device__ __forceinline__ void hidden_layer(const V* fin, V* fout, ST& st, int cbase,
                                              const float* bias, int tile0, int h) {
     APipe<V> p;
-    f32x16 prev;
+    f32x16 prev, nextb = load_bias(bias, tile0, h);
 #pragma unroll
     for (int o = 0; o < NT; ++o) {
-        f32x16 acc = load_bias(bias, tile0 + o, h);
+        f32x16 acc = nextb;
         constexpr int T = HU * NT;
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             acc = Op<V>::mfma(next_a<V, T, true, PG_PIPE_H>(p, st, o * HU + u), fin[u], acc);
-            if (u == 3 && o > 0) relu_pack<V>(prev, fout[2 * (o - 1)], fout[2 * (o - 1) + 1], true);
+            if (u == PG_RELU_AT && o > 0) {
+                // pinned: hoisted to the tile boundary the conversions wait out the last MFMA
+                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
+                relu_pack<V>(prev, fout[2 * (o - 1)], fout[2 * (o - 1) + 1], true);
+                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
+            }
+            // the next tile's bias is read mid-tile (the volatile ring reads pin it here), not at
+            // the boundary where the first MFMA would wait out the LDS latency
+            if (PG_PIN_TILE && u == PG_BIAS_AT && o + 1 < NT) nextb = load_bias(bias, tile0 + o + 1, h);
         }
+        if (!PG_PIN_TILE && o + 1 < NT) nextb = load_bias(bias, tile0 + o + 1, h);
         prev = acc;
     }
     relu_pack<V>(prev, fout[2 * (NT - 1)], fout[2 * (NT - 1) + 1], true);
@@ -522,30 +540,28 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         hidden_layer<V>(fb, fa, st, C_L6 + 0 * CH_HID, bias, BT_LAYER0 + 6 * NT, h);
         hidden_layer<V>(fa, fb, st, C_L6 + 1 * CH_HID, bias, BT_LAYER0 + 7 * NT, h);
         PG_STAMP(5);
-        // ---- heads: feature (no activation) and sigma ----
+        // ---- sigma head and the view layer's trunk part.  feature_linear has no activation, so
+        // the host folds it into the view weights (pg_pack.cpp NetTensors::fold): one segment of
+        // 1 + 4 out tiles on the last trunk activation instead of 9 + 4 ----
         float sigma;
-        APipe<V> pfa;
-#pragma unroll
-        for (int o = 0; o < NT + 1; ++o) {
-            f32x16 acc = load_bias(bias, BT_FEAT + o, h);      // tile 8 = BT_ALPHA
-            row_tile<V, HU * (NT + 1), true>(acc, pfa, st, o, fb);
-            if (o < NT) relu_pack<V>(acc, fa[2 * o], fa[2 * o + 1], false);
-            else sigma = acc[0];
-        }
-        PG_STAMP(6);
         dump_frags<V, HU>(a, 7, gp, valid, fb, h);
-        dump_frags<V, HU>(a, 8, gp, valid, fa, h);
-        // ---- view layer: [feature(256), xd(648) (, code16)] -> 128, relu ----
         V fg[HU / 2];
         {
             f32x16 acc[NTV];
             APipe<V> pv;
             [[maybe_unused]] APipeX<V> pd;
             [[maybe_unused]] constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
+            constexpr int TAV = HU * (NTV + 1);
+            {
+                f32x16 a0 = load_bias(bias, BT_ALPHA, h);
+                row_tile<V, TAV, true>(a0, pv, st, 0, fb);
+                sigma = a0[0];
+            }
+            PG_STAMP(6);
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
-                acc[o] = load_bias(bias, BT_VIEW + o, h);
-                row_tile<V, HU * NTV, true>(acc[o], pv, st, o, fa);
+                acc[o] = load_bias(bias, BT_VIEWF + o, h);
+                row_tile<V, TAV, true>(acc[o], pv, st, 1 + o, fb);
             }
             float wd[JH];
 #pragma unroll

@@ -141,13 +141,14 @@ PG_HD constexpr int vy_slot_joint(int u, int h, int e, bool fc) {
     return (fc && h == 0 && e == 4) ? JC : -1;
 }
 
-// bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1)
+// bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1), folded view (4)
 constexpr int BT_LAYER0 = 0;
 constexpr int BT_FEAT = 64;
 constexpr int BT_ALPHA = 72;
 constexpr int BT_VIEW = 73;
 constexpr int BT_RGB = 77;
-constexpr int BT_COUNT = 78;
+constexpr int BT_VIEWF = 78;    // 4 tiles: b_view + W_view[:, :256] b_feature (feature layer folded, 16-bit kernels)
+constexpr int BT_COUNT = 82;
 constexpr int BIAS_FLOATS = BT_COUNT * 32;   // [tile][h][r]
 
 }  // namespace pgl

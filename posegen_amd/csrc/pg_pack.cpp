@@ -64,12 +64,34 @@ float NetTensors::w(int mat, int row, int col) const {
     else if (mat == MAT_ALPHA) { p = alpha_w; rows = 1; cols = W; }
     else if (mat == MAT_VIEW) { p = view_w; rows = VW; cols = view_cols; }
     else if (mat == MAT_RGB) { p = rgb_w; rows = 3; cols = VW; }
+    else if (mat == MAT_ALPHA_VIEWF) {
+        if (row < 32) { p = alpha_w; rows = 1; cols = W; }
+        else { p = viewf_w.data(); rows = VW; cols = W; row -= 32; }
+    }
     else if (mat == MAT_FEAT_ALPHA) {
         if (row < W) { p = feat_w; rows = W; cols = W; }
         else { p = alpha_w; rows = 1; cols = W; row -= W; }
     }
     if (!p || row < 0 || row >= rows || col < 0 || col >= cols) return 0.f;
     return p[(size_t)row * cols + col];
+}
+
+// feature = W_f h + b_f enters the view layer linearly (no activation in between), so
+// W_view[:, :256] feature = (W_view[:, :256] W_f) h + W_view[:, :256] b_f.  Products in double.
+void NetTensors::fold() {
+    viewf_w.assign((size_t)VW * W, 0.f);
+    viewf_b.assign(VW, 0.f);
+    for (int o = 0; o < VW; ++o) {
+        const float* vr = view_w + (size_t)o * view_cols;
+        double bsum = view_b ? view_b[o] : 0.0;
+        for (int m = 0; m < W; ++m) bsum += (double)vr[m] * (feat_b ? feat_b[m] : 0.f);
+        viewf_b[o] = (float)bsum;
+        for (int k = 0; k < W; ++k) {
+            double acc = 0.0;
+            for (int m = 0; m < W; ++m) acc += (double)vr[m] * feat_w[(size_t)m * W + k];
+            viewf_w[(size_t)o * W + k] = (float)acc;
+        }
+    }
 }
 
 static std::vector<Segment> program(int shape, bool fc, bool fact) {
@@ -82,12 +104,12 @@ static std::vector<Segment> program(int shape, bool fc, bool fact) {
     s.push_back({MAT_L0 + 5, NT, true, {{SEQ_X, XSEQ, 0}}});
     for (int l = 6; l <= 7; ++l) s.push_back({MAT_L0 + l, NT, km, {hid(0)}});
     if (shape == SHAPE_A) {
-        s.push_back({MAT_FEAT_ALPHA, NT + 1, false, {hid(0)}});
+        s.push_back({MAT_ALPHA_VIEWF, NTV + 1, false, {hid(0)}});
     } else {
         s.push_back({MAT_FEAT, NT, true, {hid(0)}});
         s.push_back({MAT_ALPHA, 1, true, {hid(0)}});
+        s.push_back({MAT_VIEW, NTV, km, {hid(0)}});
     }
-    s.push_back({MAT_VIEW, NTV, km, {hid(0)}});
     if (!fact) {
         Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
         if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
@@ -105,6 +127,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3;
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
     if (fact && shape != SHAPE_A) return -3;
+    if (shape == SHAPE_A && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
@@ -187,6 +210,8 @@ void pack_bias(const NetTensors& t, std::vector<float>& out) {
     put(BT_ALPHA, t.alpha_b, 1, 0);
     for (int o = 0; o < NTV; ++o) put(BT_VIEW + o, t.view_b, VW, 32 * o);
     put(BT_RGB, t.rgb_b, 3, 0);
+    if (t.viewf_b.size() == (size_t)VW)
+        for (int o = 0; o < NTV; ++o) put(BT_VIEWF + o, t.viewf_b.data(), VW, 32 * o);
 }
 
 }  // namespace pgpack

@@ -21,6 +21,9 @@ struct NetTensors {
     const float* view_w = nullptr;  const float* view_b = nullptr;
     int view_cols = 0;
     const float* rgb_w = nullptr;   const float* rgb_b = nullptr;
+    // W_view[:, :256] W_feature [128,256] and b_view + W_view[:, :256] b_feature [128] (fold())
+    std::vector<float> viewf_w, viewf_b;
+    void fold();
     float w(int mat, int row, int col) const;
 };
 

@@ -15,7 +15,8 @@ using namespace pgl;
 
 enum Seq { SEQ_X = 0, SEQ_H = 1, SEQ_D = 2, SEQ_CODE = 3 };
 enum Mat { MAT_L0 = 0, /* .. MAT_L7 = 7 */ MAT_FEAT = 8, MAT_ALPHA = 9, MAT_VIEW = 10, MAT_RGB = 11,
-           MAT_FEAT_ALPHA = 12 /* tiles 0..7 feature_linear, tile 8 row 0 alpha_linear */ };
+           MAT_FEAT_ALPHA = 12 /* tiles 0..7 feature_linear, tile 8 row 0 alpha_linear */,
+           MAT_ALPHA_VIEWF = 13 /* tile 0 row 0 alpha_linear, tiles 1..4 W_view[:, :256] W_feature */ };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -33,18 +34,18 @@ constexpr int C_L1 = C_L0 + CH_L0X;           // L1..L4 consecutive
 constexpr int C_L5H = C_L1 + 4 * CH_HID;
 constexpr int C_L5X = C_L5H + CH_HID;
 constexpr int C_L6 = C_L5X + CH_L0X;          // L6, L7 consecutive
-constexpr int C_FA = C_L6 + 2 * CH_HID;
-constexpr int CH_FA = cdiv(HU * (NT + 1), UPC);
-constexpr int C_VF = C_FA + CH_FA;
-constexpr int CH_VF = cdiv(HU * NTV, UPC);
-constexpr int C_VD = C_VF + CH_VF;
+// feature_linear has no activation (nerf.py:103-110), so it is folded into the view layer on the
+// host: one out-tile-major segment [alpha | W_view[:, :256] W_feature] on the last trunk output
+constexpr int C_AV = C_L6 + 2 * CH_HID;
+constexpr int CH_AV = cdiv(HU * (NTV + 1), UPC);
+constexpr int C_VD = C_AV + CH_AV;
 constexpr int CH_VD = cdiv((DU + 1) * NTV, UPC);
 constexpr int C_RGB = C_VD + CH_VD;
 constexpr int NCHUNK = C_RGB + 1;
 static_assert(cdiv(DU * NTV, UPC) == CH_VD, "view segment must take the same chunks with and without frame code");
 // MFMAs issued per 32-point group (for pg_query / roofline bookkeeping)
 constexpr int MFMA_PER_GROUP(bool fc) {
-    return XU * NT * 2 + 6 * HU * NT + HU * NT /*L5h*/ + HU * 9 + HU * NTV + (DU + (fc ? 1 : 0)) * NTV + 8;
+    return XU * NT * 2 + 6 * HU * NT + HU * NT /*L5h*/ + HU * (NTV + 1) + (DU + (fc ? 1 : 0)) * NTV + 8;
 }
 }  // namespace A
 
@@ -54,7 +55,7 @@ namespace AF {
 static_assert(A::UPC == 8 * VY_UPW, "Y stage: 8 waves x VY_UPW units per chunk");
 constexpr int CH_VY(bool fc) { return cdiv(2 * (JH + (fc ? 1 : 0)), VY_UPW); }     // 6 / 7
 constexpr int NCHUNK(bool fc) {
-    return CH_VY(fc) + 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_FA + A::CH_VF + 1;
+    return CH_VY(fc) + 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_AV + 1;
 }
 // MFMAs per 32-point group: the trunk as in A, 2*(12|13) Y-stage + 8 or 16 second-stage ones
 constexpr int MFMA_PER_GROUP(bool fc) {

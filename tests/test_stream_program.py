@@ -19,7 +19,7 @@ from tests.helpers import oracle_cfg
 
 J, JH, LV, LD, W, NT, VW, NTV = 24, 12, 7, 4, 256, 8, 128, 4
 XSEQ, HSEQ, DSEQ_MAIN, DSEQ = 216, 128, 288, 328
-BT_FEAT, BT_ALPHA, BT_VIEW, BT_RGB = 64, 72, 73, 77
+BT_FEAT, BT_ALPHA, BT_VIEW, BT_RGB, BT_VIEWF = 64, 72, 73, 77, 78
 
 
 def rho(r, h):
@@ -59,7 +59,7 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), None, 0, C.byref(size), None, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
     buf = np.zeros(size.value, dtype=np.uint8)
-    bias = np.zeros(78 * 32, dtype=np.float32)
+    bias = np.zeros(82 * 32, dtype=np.float32)
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
@@ -204,14 +204,16 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
         tiles = segment(NT, km, [(hv, HSEQ)], l * NT)
         hv, _ = hidden_vals(tiles)
     if shape_a:
-        fa = segment(NT + 1, False, [(hv, HSEQ)], BT_FEAT)
-        sigma = fa[NT][0]
-        feat = fa[:NT]
+        # feature layer folded into the view weights: tiles [alpha | view x 4] on the trunk output
+        av = segment(NTV + 1, False, [(hv, HSEQ)], BT_ALPHA,
+                     acc=[bias_tile(BT_ALPHA)] + [bias_tile(BT_VIEWF + o) for o in range(NTV)])
+        sigma = av[0][0]
+        vt = av[1:]
     else:
         feat = segment(NT, True, [(hv, HSEQ)], BT_FEAT)
         sigma = segment(1, True, [(hv, HSEQ)], BT_ALPHA)[0][0]
-    fv, _ = hidden_vals(feat, relu=False)
-    vt = segment(NTV, km, [(fv, HSEQ)], BT_VIEW)
+        fv, _ = hidden_vals(feat, relu=False)
+        vt = segment(NTV, km, [(fv, HSEQ)], BT_VIEW)
     if fact is not None:
         wq = q16(fact[1].astype(np.float32), prec)                  # [pt, 24]
         for u in range(2):
