@@ -187,6 +187,11 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
                   int64_t* stream_bytes, float* bias_out /* 82*32 floats or NULL */,
                   int32_t* chunk_bytes /* out: ring chunk size the library was built with */);
 
+/* Host-only: the Y-stage weights of the factorised view layer (16-bit precisions), laid out
+ * [wave 8][unit][64 lanes x 16 B] as the kernel reads them.  out may be NULL to query the size. */
+int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
+                     int precision, uint8_t* out, int64_t cap, int64_t* out_bytes);
+
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision. */
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group);

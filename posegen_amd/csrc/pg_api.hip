@@ -42,6 +42,7 @@ struct NetState {
     std::vector<float> codes_host;             // [n_codes+1,16]
     int n_codes = 0;
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
+    uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the factorised view layer
     size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
     float* d_codes = nullptr;
@@ -132,6 +133,13 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec][fact]), packed.size()));
     PG_HIP(h, hipMemcpy(ns.d_stream[prec][fact], packed.data(), packed.size(), hipMemcpyHostToDevice));
     ns.stream_bytes[prec][fact] = packed.size();
+    if (fact && !ns.d_vy[prec]) {
+        std::vector<uint8_t> vy;
+        if (pgpack::pack_vy(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, vy) != 0)
+            return fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_vy[prec]), vy.size()));
+        PG_HIP(h, hipMemcpy(ns.d_vy[prec], vy.data(), vy.size(), hipMemcpyHostToDevice));
+    }
     return PG_OK;
 }
 
@@ -167,6 +175,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.rays = rays; a.z = z; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
     a.wstream = ns.d_stream[prec][fact];
+    a.wy = fact ? ns.d_vy[prec] : nullptr;
     a.bias = ns.d_bias;
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
@@ -259,6 +268,7 @@ void pg_destroy(pg_handle* h) {
     (void)hipDeviceSynchronize();
     for (NetState& ns : h->net) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
+        for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
     }
@@ -297,6 +307,8 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     for (int p = 0; p < PG_PREC_COUNT; ++p)
         for (int f = 0; f < 2; ++f)
             if (ns.d_stream[p][f]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p][f])); ns.d_stream[p][f] = nullptr; }
+    for (int p = 0; p < PG_PREC_COUNT; ++p)
+        if (ns.d_vy[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vy[p])); ns.d_vy[p] = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
@@ -403,6 +415,25 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
         std::vector<float> bias;
         pgpack::pack_bias(tensors_of(ns, cfg), bias);
         std::memcpy(bias_out, bias.data(), bias.size() * sizeof(float));
+    }
+    return PG_OK;
+}
+
+int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
+                     int precision, uint8_t* out, int64_t cap, int64_t* out_bytes) {
+    if (!tensors || !shapes || n_tensors != 24) return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: need 24 tensors");
+    NetState ns;
+    ns.host.assign(24, {});
+    for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + shapes[2 * i] * shapes[2 * i + 1]);
+    pg_config cfg{};
+    cfg.framecode_ch = framecode_ch;
+    std::vector<uint8_t> vy;
+    if (pgpack::pack_vy(tensors_of(ns, cfg), precision, framecode_ch > 0, vy) != 0)
+        return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: 16-bit precisions only");
+    if (out_bytes) *out_bytes = (int64_t)vy.size();
+    if (out) {
+        if ((int64_t)vy.size() > cap) return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: buffer too small");
+        std::memcpy(out, vy.data(), vy.size());
     }
     return PG_OK;
 }

@@ -19,6 +19,7 @@ struct EvalArgs {
     const float* cams;        // [n] frame-code index (float) or null
     const float* codes;       // [n_codes+1,16], last row = mean code; null if no frame code
     const uint8_t* wstream;   // packed weights (pg_pack.cpp)
+    const uint8_t* wy;        // Y-stage weights of the factorised view layer (pack_vy), or null
     const float* bias;        // BIAS_FLOATS
     const float* cutoff;      // [48] = cutoff_dist of embed_fn (24) then embeddirs_fn (24)
     float* raw;               // [n*S,4] (rgb_raw, sigma_raw)
@@ -125,9 +126,20 @@ struct Stream {
     // in the texture addresser and every wave stalls on the issue.
     uint32_t cur_src, cur_dst;   // stream byte offset / ring byte offset of this wave's share
     __device__ __forceinline__ void enter_split() {
+#if defined(PG_STAMPS)
+        unsigned long long s0, s1, s2;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0)::"memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s1)::"memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s2)::"memory");
+        t_vm += s1 - s0;
+        t_bar += s2 - s1;
+#else
         if (dma_wave()) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         cur_src = next_off + (wave - dma_base()) * (PER * 1024);
         cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
         next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;

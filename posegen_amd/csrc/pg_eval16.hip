@@ -27,6 +27,7 @@ constexpr int PTS = NWAVE * 32;     // points per workgroup pass
 
 template <typename V> struct Op;
 template <> struct Op<bf16x8> {
+    using E = __bf16;
     static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -38,6 +39,7 @@ template <> struct Op<bf16x8> {
     }
 };
 template <> struct Op<f16x8> {
+    using E = _Float16;
     static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -60,7 +62,7 @@ template <> struct Op<f16x8> {
 #endif
 // FACT selects the factorised view layer (pg_layout.h) and with it the stream program
 template <bool FACT, bool FC>
-using StreamOf = Stream<NWAVE, (FACT ? pgp::AF::NCHUNK(FC) : NCHUNK), PG_DMA_WAVES>;
+using StreamOf = Stream<NWAVE, (FACT ? pgp::AF::NCHUNK : NCHUNK), PG_DMA_WAVES>;
 static_assert(PG_DMA_WAVES == NWAVE || PG_SPREAD_DMA, "the bulk enter() waits vmcnt on every wave");
 
 __device__ __forceinline__ const float* opaque_ptr(const float* p) {
@@ -352,52 +354,44 @@ __device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r
 
 // Y stage: Y[ray][j][o] for the rays of this pass.  Wave w: out tile w&3, the 12 (13 with the
 // frame code) joints of half w>>2; per joint two K=16 MFMAs with A = T16 (rows = rays) and
-// B = the wave's weight units of the current chunk (pg_pack.cpp).  C has the out channel on
-// the lane and rays 0..3 (lanes < 32) / 4..7 in registers 0..3: eight joints' worth of one
-// ray make the 16 bytes lane (h, o) of the second stage's A fragment (tile, u) holds.
-template <typename V, bool FC, typename ST>
-__device__ __forceinline__ void y_stage(ST& st, uint8_t* rt, int nr, int wave, int lane) {
+// B = the wave's own weight units (pack_vy), read straight from L2 into registers at the top of
+// the pass (no other wave needs them, so they do not go through the LDS ring).  C has the out
+// channel on the lane and rays 0..3 (lanes < 32) / 4..7 in registers 0..3; joint e of the wave
+// lands in 16-bit slot e%8 of the 16 bytes lane (h, o) of the second stage's A fragment
+// (tile, e/8) holds.
+template <typename V, bool FC>
+struct YWeights {
+    static constexpr int NU = pgp::AF::VY_UNITS(FC);
+    uint4 b[NU];
+    __device__ __forceinline__ void load(const EvalArgs& a, int wave, int lane) {
+        const uint4* p = reinterpret_cast<const uint4*>(a.wy) + ((size_t)wave * NU) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NU; ++n) b[n] = p[n * 64];
+    }
+};
+
+template <typename V, bool FC>
+__device__ __forceinline__ void y_stage(const YWeights<V, FC>& yw, uint8_t* rt, int nr, int wave, int lane) {
     constexpr int NE = JH + (FC ? 1 : 0);
-    constexpr int NCH = pgp::AF::CH_VY(FC);
+    using E = typename Op<V>::E;
     const int t = wave & 3, hw = wave >> 2, hl = lane >> 5, col = lane & 31;
     const uint8_t* trow = rt + min(col, nr - 1) * SLOTF_BYTES + SLOTF_T16 + hl * 16;
     const uint8_t* trow_h = trow + hw * (JH * TK * 2);
     uint8_t* ybase = rt + SLOTF_Y + ((t * 2) * 64 + 32 * hw + col) * 16 + 4 * hl * SLOTF_BYTES;
-    float yv[4][8];
-    f32x16 acc;
 #pragma clang loop unroll(full)
-    for (int c = 0; c < NCH; ++c) {
-        st.enter_split();
+    for (int e = 0; e < NE; ++e) {
+        const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
+        const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj));
+        const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj + 32));
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < ST::PER; ++i) st.piece(i);
-#pragma clang loop unroll(full)
-        for (int i = 0; i < VY_UPW; ++i) {
-            const int n = c * VY_UPW + i, e = n / 2, ku = n % 2;
-            if (e >= NE) continue;
-            const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
-            const V av = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj + ku * 32));
-            const V bv = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(0, (wave * VY_UPW + i) * UNIT_BYTES)));
-            if (ku == 0) {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = Op<V>::mfma(a0, __builtin_bit_cast(V, yw.b[2 * e]), acc);
+        acc = Op<V>::mfma(a1, __builtin_bit_cast(V, yw.b[2 * e + 1]), acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            }
-            acc = Op<V>::mfma(av, bv, acc);
-            if (ku == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r][e % 8] = acc[r];
-                if (e == 7 || e == NE - 1) {
-                    const int u = e / 8;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                        for (int ee = (e % 8) + 1; ee < 8; ++ee) yv[r][ee] = 0.0f;
-                        // ray = r + 4 hl; only MAXR_F = 5 slots exist
-                        if (hl == 0 || r == 0)
-                            *reinterpret_cast<V*>(ybase + r * SLOTF_BYTES + u * 1024) = Op<V>::cvt(yv[r]);
-                    }
-                }
-            }
-        }
+        for (int r = 0; r < 4; ++r)        // ray = r + 4 hl; only MAXR_F = 5 slots exist
+            if (hl == 0 || r == 0)
+                *reinterpret_cast<E*>(ybase + r * SLOTF_BYTES + (e / 8) * 1024 + (e % 8) * 2) = (E)acc[r];
     }
 }
 
@@ -452,6 +446,10 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    if (FACT) {     // the pad slots of the Y fragments are read (times a zero weight) but never written
+        for (int i = tid; i < MAXR_F * (4 * 2 * 1024 / 16); i += NTHR)
+            *reinterpret_cast<uint4*>(rtf + (i / 512) * SLOTF_BYTES + SLOTF_Y + (i % 512) * 16) = make_uint4(0, 0, 0, 0);
+    }
     st.start();
 
 #if defined(PG_STAMPS)
@@ -463,11 +461,13 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const long long plast = min(p0 + PTS - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
+        [[maybe_unused]] YWeights<V, FC> yw;
+        if (FACT) yw.load(a, wave, lane);       // in flight across the barrier and the table build
         lds_barrier();                          // previous pass is done with the table
         if (FACT) {
             ray_tablef<V, FC, NTHR>(a, rtf, r0, nr);
             lds_barrier();
-            y_stage<V, FC>(st, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
+            y_stage<V, FC>(yw, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
         } else {
             ray_table_phase1<NTHR>(a, rtab, r0, nr);
             lds_barrier();

@@ -124,7 +124,6 @@ constexpr int SLOTF_T16 = J * 32;       // 768: 25 joints x TK 16-bit values
 constexpr int SLOTF_Y = SLOTF_T16 + (J + 1) * TK * 2;   // 2368: [tile 4][u 2][64 lanes] x 16 B
 constexpr int SLOTF_BYTES = SLOTF_Y + 4 * 2 * 1024;     // 10560
 static_assert(SLOTF_T16 % 16 == 0 && SLOTF_Y % 16 == 0 && SLOTF_BYTES % 16 == 0, "LDS alignment");
-constexpr int VY_UPW = 4;               // stream units per wave per 32-unit chunk in the Y stage
 // view-input column (0 .. 647 + 16) multiplied by value k of joint j; -1 = zero pad
 PG_HD constexpr int vd_channel(int j, int k) {
     if (j < J) return k < 3 * ROWS_D ? (k % ROWS_D) * (3 * J) + 3 * j + k / ROWS_D : -1;

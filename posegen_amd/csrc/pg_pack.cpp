@@ -132,29 +132,6 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
     if (seg_chunk_base) seg_chunk_base->clear();
-    auto put16 = [&](size_t at, float wv) {
-        const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
-        std::memcpy(&out[at], &hi, 2);
-    };
-    if (fact) {
-        // Y stage: chunk c holds, for every wave w, its units 4c..4c+3 at positions 4w..4w+3.
-        // Unit n of wave w = (joint e = n/2, k-unit ku = n%2) of out tile w&3 as a B operand:
-        // lane (hl, col) = out channel 32(w&3)+col, values k = 16ku + 8hl + 0..7 of that joint.
-        if (seg_chunk_base) seg_chunk_base->push_back(0);
-        for (int c = 0; c < AF::CH_VY(fc); ++c)
-            for (int w = 0; w < 8; ++w)
-                for (int i = 0; i < VY_UPW; ++i) {
-                    const int n = c * VY_UPW + i, j = vy_joint(w, n / 2, fc), ku = n % 2;
-                    const size_t base = out.size();
-                    out.resize(base + 1024, 0);
-                    if (j < 0) continue;
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int ch = vd_channel(j, 16 * ku + 8 * (lane >> 5) + e);
-                            if (ch >= 0) put16(base + lane * 16 + e * 2, t.w(MAT_VIEW, 32 * (w & 3) + (lane & 31), W + ch));
-                        }
-                }
-    }
     for (const Segment& sg : program(shape, fc, fact)) {
         if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
         // flatten the input units of this segment
@@ -190,8 +167,30 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         }
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK(fc) : A::NCHUNK) : B::NCHUNK;
+    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK) : B::NCHUNK;
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
+    return 0;
+}
+
+int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& out) {
+    if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
+    const bool is_bf = precision == PG_PREC_BF16;
+    out.assign((size_t)AF::VY_BYTES(fc), 0);
+    for (int w = 0; w < 8; ++w)
+        for (int n = 0; n < AF::VY_UNITS(fc); ++n) {
+            const int j = vy_joint(w, n / 2, fc), ku = n % 2;
+            if (j < 0) continue;
+            const size_t base = ((size_t)w * AF::VY_UNITS(fc) + n) * UNIT_BYTES;
+            // lane (hl, col) = out channel 32(w&3)+col, values k = 16ku + 8hl + 0..7 of joint j
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = vd_channel(j, 16 * ku + 8 * (lane >> 5) + e);
+                    if (ch < 0) continue;
+                    const float wv = t.w(MAT_VIEW, 32 * (w & 3) + (lane & 31), W + ch);
+                    const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
+                    std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                }
+        }
     return 0;
 }
 

@@ -32,5 +32,8 @@ struct NetTensors {
 int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base = nullptr);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
+// Y-stage weights of the factorised view layer: [wave 8][unit n][64 lanes x 16 B]; unit n of
+// wave w = (joint vy_joint(w, n/2), k-unit n%2) of out tile w&3 as an MFMA B operand.
+int pack_vy(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out);
 
 }  // namespace pgpack

@@ -50,16 +50,15 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 }  // namespace A
 
 // ---------------- shape A with the factorised view layer (pg_layout.h) ---------------
-// [Y stage][L0][L1..4][L5h][L5x][L6][L7][feature+alpha][view <- feature][rgb]
+// stream: [L0][L1..4][L5h][L5x][L6][L7][alpha+view][rgb]; the Y-stage weights are a separate
+// per-wave array read straight from L2 into registers (VY_UNITS units of 1 KiB per wave)
 namespace AF {
-static_assert(A::UPC == 8 * VY_UPW, "Y stage: 8 waves x VY_UPW units per chunk");
-constexpr int CH_VY(bool fc) { return cdiv(2 * (JH + (fc ? 1 : 0)), VY_UPW); }     // 6 / 7
-constexpr int NCHUNK(bool fc) {
-    return CH_VY(fc) + 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_AV + 1;
-}
+constexpr int VY_UNITS(bool fc) { return 2 * (JH + (fc ? 1 : 0)); }                // 24 / 26
+constexpr int VY_BYTES(bool fc) { return 8 * VY_UNITS(fc) * UNIT_BYTES; }
+constexpr int NCHUNK = 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_AV + 1;
 // MFMAs per 32-point group: the trunk as in A, 2*(12|13) Y-stage + 8 or 16 second-stage ones
 constexpr int MFMA_PER_GROUP(bool fc) {
-    return A::MFMA_PER_GROUP(false) - A::DU * NTV + 2 * (JH + (fc ? 1 : 0)) + 8;
+    return A::MFMA_PER_GROUP(false) - A::DU * NTV + VY_UNITS(fc) + 8;
 }
 }  // namespace AF
 

@@ -120,13 +120,16 @@ print("rank", rank, "ok")
 def test_gather_frames_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), REPO]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    for attempt in range(3):        # the probed port can be taken again before torchrun binds it
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), REPO]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        if out.returncode == 0 or "address already in use" not in (out.stdout + out.stderr).lower():
+            break
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
 

@@ -63,7 +63,15 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
-    return buf, bias, chunk.value
+    if fact:
+        n = C.c_int64()
+        rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(n))
+        assert rc == 0, lib.pg_last_error(None)
+        vy = np.zeros(n.value, dtype=np.uint8)
+        rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, vy.ctypes.data, n.value, C.byref(n))
+        assert rc == 0, lib.pg_last_error(None)
+        return buf, bias, chunk.value, vy
+    return buf, bias, chunk.value, None
 
 
 class Wave:
@@ -123,19 +131,19 @@ def vy_slot_joint(u, h, e, fc):
     return J if fc and h == 0 and e == 4 else -1
 
 
-def y_stage(wv, tray, fc, prec):
-    """Y[25, 128] of one ray from the leading Y-stage chunks (pg_pack.cpp, pg_eval16.hip y_stage):
-    wave w multiplies its units (chunk n//4, position 4w + n%4) as B operands (lane (hl, o):
-    k = 16ku + 8hl + e) with the ray's 16-bit view values T16[j][k]."""
+def y_stage(vy, tray, fc, prec):
+    """Y[25, 128] of one ray (pg_pack.cpp pack_vy, pg_eval16.hip y_stage): wave w multiplies its
+    units (unit n = joint n//2, k-unit n%2) as B operands (lane (hl, o): k = 16ku + 8hl + e)
+    with the ray's 16-bit view values T16[j][k]."""
     ne = JH + (1 if fc else 0)
-    nch = -(-2 * ne // 4)
+    assert vy.size == 8 * 2 * ne * 1024
     t16 = q16(tray.astype(np.float32), prec)
     y = np.zeros((J + 1, VW), dtype=np.float32)
     for w in range(8):
         for n in range(2 * ne):
             j, ku = vy_joint(w, n // 2, fc), n % 2
-            off = (n // 4) * wv.cb + (4 * w + n % 4) * 1024
-            unit = wv.s[off:off + 1024].reshape(64, 16)
+            off = (w * 2 * ne + n) * 1024
+            unit = vy[off:off + 1024].reshape(64, 16)
             vals = ((unit.view(np.uint16).astype(np.uint32) << 16).view(np.float32) if prec == PREC_BF16
                     else unit.view(np.float16).astype(np.float32)).reshape(2, 32, 8)      # [hl, o, e]
             if j < 0:
@@ -143,16 +151,13 @@ def y_stage(wv, tray, fc, prec):
                 continue
             kk = t16[j, 16 * ku:16 * ku + 16].reshape(2, 8)
             y[j, 32 * (w & 3):32 * (w & 3) + 32] += np.einsum("he,hoe->o", kk, vals)
-    wv.chunk = nch - 1
     return q16(y, prec)
 
 
 def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
     """x: [32 pts, 1080(+code16)] oracle input rows -> raw [32, 4] through the packed stream.
-    fact = (tray [25,32], wpt [32,24]): the factorised view layer with x[:,432:1080] = wpt (x) tray."""
+    fact = (tray [25,32], wpt [32,24], vy): the factorised view layer with x[:,432:1080] = wpt (x) tray."""
     wv = Wave(stream, chunk_bytes, prec)
-    if fact is not None:
-        yq = y_stage(wv, fact[0], bool(cfg.framecode_ch), prec)
     shape_a = prec in (PREC_BF16, PREC_FP16)
     ue = wv.ue
 
@@ -215,6 +220,7 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
         fv, _ = hidden_vals(feat, relu=False)
         vt = segment(NTV, km, [(fv, HSEQ)], BT_VIEW)
     if fact is not None:
+        yq = y_stage(fact[2], fact[0], bool(cfg.framecode_ch), prec)
         wq = q16(fact[1].astype(np.float32), prec)                  # [pt, 24]
         for u in range(2):
             for h in range(2):
@@ -247,7 +253,7 @@ def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
         pytest.skip("the fp32 kernel keeps the direct view layer")
     cfg = h36m_config() if fc else surreal_config()
     w = syn.make_weights(cfg, 3)
-    stream, bias, chunk_bytes = pack(w, cfg, prec, fact)
+    stream, bias, chunk_bytes, vy = pack(w, cfg, prec, fact)
     rng = np.random.RandomState(0)
     x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
     x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)     # cutoff-weighted magnitudes
@@ -259,7 +265,7 @@ def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
         for j in range(J):
             for k in range(27):
                 x[:, 432 + vd_channel(j, k)] = wpt[:, j] * tray[j, k]
-        fact_in = (tray, wpt)
+        fact_in = (tray, wpt, vy)
     ocfg = oracle_cfg(cfg, 79.6, 79.6)
     ocfg.quant = quant
     tw = {k: torch.tensor(v) for k, v in w.items()}

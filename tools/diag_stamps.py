@@ -18,10 +18,10 @@ st = full[:, :, :9]
 print("per pass per wave: cycles waiting in vmcnt (weight DMA) %.0f, in s_barrier %.0f" % (full[1:, :, 9].mean(), full[1:, :, 10].mean()))
 print("   by wave: vmcnt", full[1:, :, 9].mean(0).astype(int).tolist(), " barrier", full[1:, :, 10].mean(0).astype(int).tolist())
 d = np.diff(st, axis=-1).astype(np.float64)     # [it, wave, 8 segments]
-names = ["ray table+setup", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "feat+alpha", "view", "rgb+store"]
+names = ["ray table+Y stage", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "alpha tile", "view (trunk+Y)", "rgb+store"]
 tot = (st[:, :, 8] - st[:, :, 0]).astype(np.float64)
 print("pass total cycles (s_memtime ticks): mean %.0f  min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
-mf = [0, 216, 512, 344, 256, 144, 228, 8]
+mf = [24, 216, 512, 344, 256, 16, 72, 8]
 for k, nme in enumerate(names):
     m = d[:, :, k].mean()
     print(f"{nme:18s} {m:9.0f} cycles  {100*m/tot.mean():5.1f}%   mfma {mf[k]:4d} -> {m/max(mf[k],1):6.1f} cyc/mfma (ideal 64 for 2 waves/SIMD)")
