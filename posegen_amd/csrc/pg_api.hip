@@ -17,6 +17,7 @@
 
 extern "C" {
 int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream);
+int pg_launch_eval16s(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
@@ -43,6 +44,8 @@ struct NetState {
     int n_codes = 0;
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
     uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the factorised view layer
+    uint8_t* d_stream_s[PG_PREC_COUNT] = {};      // 16x16x32 kernel (pg_eval16s.hip): stream, bias table
+    float* d_bias_s = nullptr;
     size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
     float* d_codes = nullptr;
@@ -122,6 +125,32 @@ bool use_fact(int prec, int S) {
     return allowed && is_shape_a(prec) && S >= FACT_MIN_S;
 }
 
+// MFMA shape of the factorised 16-bit kernel: 32x32x16 (pg_eval16.hip); POSEGEN_MFMA=16 selects
+// the 16x16x32 variant (pg_eval16s.hip), which measured the same wall time
+bool use_small_tiles() {
+    static const bool on = [] { const char* e = std::getenv("POSEGEN_MFMA"); return e && std::strcmp(e, "16") == 0; }();
+    return on;
+}
+
+int ensure_stream_s(pg_handle* h, int which, int prec) {
+    NetState& ns = h->net[which];
+    if (ns.d_stream_s[prec]) return PG_OK;
+    std::vector<uint8_t> packed;
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    const int rc = pgpack::pack_stream_s(t, prec, packed);
+    if (rc != 0) return fail(h, PG_EINVAL, "16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_s[prec]), packed.size()));
+    PG_HIP(h, hipMemcpy(ns.d_stream_s[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
+    if (!ns.d_bias_s) {
+        std::vector<float> b;
+        pgpack::pack_bias_s(t, b);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias_s), b.size() * sizeof(float)));
+        PG_HIP(h, hipMemcpy(ns.d_bias_s, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return PG_OK;
+}
+
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -168,15 +197,17 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool fact = use_fact(prec, S);
     int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
+    const bool small = fact && use_small_tiles();
+    if (small && (rc = ensure_stream_s(h, which, prec))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = ns.d_stream[prec][fact];
+    a.wstream = small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
     a.wy = fact ? ns.d_vy[prec] : nullptr;
-    a.bias = ns.d_bias;
+    a.bias = small ? ns.d_bias_s : ns.d_bias;
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
     a.pose_stride = pose_stride;
@@ -205,7 +236,8 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         PG_HIP(h, get(e1));
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
-    int e = sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
+    int e = small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
+          : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
         PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
@@ -269,6 +301,8 @@ void pg_destroy(pg_handle* h) {
     for (NetState& ns : h->net) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
+        for (auto& p : ns.d_stream_s) if (p) (void)hipFree(p);
+        if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
     }
@@ -307,8 +341,11 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     for (int p = 0; p < PG_PREC_COUNT; ++p)
         for (int f = 0; f < 2; ++f)
             if (ns.d_stream[p][f]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p][f])); ns.d_stream[p][f] = nullptr; }
-    for (int p = 0; p < PG_PREC_COUNT; ++p)
+    for (int p = 0; p < PG_PREC_COUNT; ++p) {
         if (ns.d_vy[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vy[p])); ns.d_vy[p] = nullptr; }
+        if (ns.d_stream_s[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_s[p])); ns.d_stream_s[p] = nullptr; }
+    }
+    if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));

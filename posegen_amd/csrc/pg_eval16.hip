@@ -13,422 +13,10 @@
 // produced on the fly as B fragments (never stored) and recomputed for the skip layer;
 // the 648-wide view input is a per-ray sin/cos table in LDS times the per-point cutoff
 // weight.
-#include "pg_device.h"
+#include "pg_eval16_common.h"
 
 namespace pgd {
 using namespace pgp::A;
-
-#ifndef PG_A_WAVES
-#define PG_A_WAVES 8
-#endif
-constexpr int NWAVE = PG_A_WAVES;          // 8: one workgroup per CU; 4: two independent workgroups per CU
-constexpr int NTHR = NWAVE * 64;
-constexpr int PTS = NWAVE * 32;     // points per workgroup pass
-
-template <typename V> struct Op;
-template <> struct Op<bf16x8> {
-    using E = __bf16;
-    static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ bf16x8 cvt(const float* x) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j];
-        return v;
-    }
-};
-template <> struct Op<f16x8> {
-    using E = _Float16;
-    static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ f16x8 cvt(const float* x) {
-        f16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)x[j];
-        return v;
-    }
-};
-
-#ifndef PG_SPREAD_DMA
-#define PG_SPREAD_DMA 1       // weight-ring refill spread over the chunk (Stream::enter_split)
-#endif
-#ifndef PG_DMA_PHASE
-#define PG_DMA_PHASE 2
-#endif
-#ifndef PG_DMA_WAVES
-#define PG_DMA_WAVES 8
-#endif
-// FACT selects the factorised view layer (pg_layout.h) and with it the stream program
-template <bool FACT, bool FC>
-using StreamOf = Stream<NWAVE, (FACT ? pgp::AF::NCHUNK : NCHUNK), PG_DMA_WAVES>;
-static_assert(PG_DMA_WAVES == NWAVE || PG_SPREAD_DMA, "the bulk enter() waits vmcnt on every wave");
-
-__device__ __forceinline__ const float* opaque_ptr(const float* p) {
-    // LDS pointers are 32-bit offsets; keep the value in one VGPR the optimizer cannot split
-    unsigned v = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
-    asm volatile("" : "+v"(v));
-    return (const float*)(const __attribute__((address_space(3))) float*)(uintptr_t)v;
-}
-
-#ifndef PG_ASYNC_X
-#define PG_ASYNC_X true       // hand-pipelined ring reads in the x segments
-#endif
-#ifndef PG_ASYNC_VD
-#define PG_ASYNC_VD true      // ... in the view-direction segment
-#endif
-
-template <typename V, typename ST>
-__device__ __forceinline__ V unit_of(ST& st, int c, int pos) {
-    return __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(c, pos * UNIT_BYTES)));
-}
-
-// Software pipeline of the A operand.  Left to hipcc, every ring read is sunk next to its MFMA
-// (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma): the whole LDS latency is exposed 1700 times per
-// pass and the MFMA pipe idles ~45 %.  The reads are therefore issued by inline asm, two units
-// ahead into a 3-register-set rotation, and retired by COUNTED lgkmcnt waits (the asm is
-// invisible to hipcc's own waitcnt bookkeeping, whose waits for its own LDS reads only become
-// more conservative).  The lookahead never crosses a chunk boundary (the next chunk is only
-// readable after its enter(), which also drains lgkmcnt).
-typedef __attribute__((ext_vector_type(4))) unsigned a128;
-#ifndef PG_EARLY_RETIRE
-#define PG_EARLY_RETIRE 0
-#endif
-#ifndef PG_PIPE_H
-#define PG_PIPE_H 3           // register sets of the A pipe in the register-light segments (hidden layers, heads)
-#endif
-#ifndef PG_PIPE_X
-#define PG_PIPE_X 3           // ... in the segments that hold 8 (x) or 4 (view) accumulator tiles
-#endif
-template <typename V, int NS = PG_PIPE_H> struct APipe { a128 r[NS]; };
-template <typename V> using APipeX = APipe<V, PG_PIPE_X>;
-
-__device__ __forceinline__ void lds_retire(a128& r, int younger) {
-    switch (younger) {   // constant after unrolling
-        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
-        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r)); break;
-        default: __builtin_unreachable();
-    }
-}
-
-// A fragment of unit L (compile-time after unrolling) of a segment with T units: NS register
-// sets, reads issued NS-1 units ahead.  ASYNC = false: a plain (compiler-scheduled) read.
-template <typename V, int T, bool ASYNC, int NS, typename ST>
-__device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
-    constexpr int PER = ST::PER, PSTRIDE = UPC / PER, LA = NS - 1;
-    const int q = L % UPC;
-    if (!ASYNC) {
-        if (q == 0) st.enter(L / UPC);
-        return unit_of<V>(st, 0, q);
-    }
-    const int rem = min(T - 1 - L, UPC - 1 - q);      // later units of this segment in this chunk
-    if (q == 0) {
-        if (PG_SPREAD_DMA) st.enter_split(); else st.enter(L / UPC);
-        for (int k = 0; k < LA; ++k)
-            if (k <= rem) st.issue(p.r[(L + k) % NS], q + k);
-    }
-    if (LA <= rem) st.issue(p.r[(L + LA) % NS], q + LA);
-    if (PG_SPREAD_DMA) {
-        // refill piece i of the freed slot goes out at unit i*PSTRIDE+PG_DMA_PHASE of this
-        // chunk; a segment ending inside the chunk flushes the rest with its last unit
-        if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
-        if (L == T - 1)
-            for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
-    }
-    if (PG_EARLY_RETIRE) {
-        // The retire "writes" its register as far as hipcc knows, and a VALU write directly
-        // before an MFMA read costs an s_nop: retire unit L+1 here, one MFMA early, so only
-        // the first unit of a chunk pays it.
-        if (q == 0) lds_retire(p.r[L % NS], min(LA, rem));
-        if (rem >= 1) lds_retire(p.r[(L + 1) % NS], min(LA, rem) - 1);
-    } else {
-        lds_retire(p.r[L % NS], min(LA, rem));
-    }
-    return __builtin_bit_cast(V, p.r[L % NS]);
-}
-
-#ifndef PG_PIN_TILE
-#define PG_PIN_TILE 1
-#endif
-#ifndef PG_RELU_AT
-#define PG_RELU_AT 3
-#endif
-#ifndef PG_BIAS_AT
-#define PG_BIAS_AT 9
-#endif
-#ifndef PG_SETPRIO
-#define PG_SETPRIO 0
-#endif
-// one B fragment against NO out tiles; unit row uu of a k-major segment with T units
-template <typename V, int NO, int T, bool ASYNC, int NS, typename ST>
-__device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, ST& st, int uu, V b) {
-    if (PG_SETPRIO) __builtin_amdgcn_s_setprio(PG_SETPRIO);
-#pragma unroll
-    for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, uu * NO + o), b, acc[o]);
-    if (PG_SETPRIO) __builtin_amdgcn_s_setprio(0);
-}
-
-// acc (+)= W[:, x-columns] * x : the 432-wide density input, generated on the fly
-// `skb` = this lane half's 12 bone rows, `cutb` its 12 cutoff distances: both are opaque
-// bases (see opaque_ptr) so that each joint is an immediate offset, not a live register.
-// bone-local position of the wave's point for joint jj of its lane half
-struct QFromRows {      // q = R p + t from the bone rows (classic table)
-    const float* skb; float px, py, pz;
-    __device__ __forceinline__ void operator()(int jj, float& qx, float& qy, float& qz) const {
-        bone_local(skb + jj * 12, px, py, pz, qx, qy, qz);
-    }
-};
-struct QFromAB {        // q = a + z b from the per-ray (a, b) table (pg_layout.h SLOTF_AB)
-    const float* ab; float z;
-    __device__ __forceinline__ void operator()(int jj, float& qx, float& qy, float& qz) const {
-        const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
-        qx = fmaf(z, hi.x, lo.x); qy = fmaf(z, hi.y, lo.y); qz = fmaf(z, hi.z, lo.z);
-    }
-};
-
-template <typename V, typename ST, typename Q>
-__device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const Q& qof,
-                                          const float* cutb, float tau) {
-    APipeX<V> p;
-    constexpr int T = XU * NT;
-#pragma clang loop unroll(full)
-    for (int sb = 0; sb < 3; ++sb) {
-        float lo[8];
-#pragma clang loop unroll(full)
-        for (int k = 0; k < 4; ++k) {
-            const int jj = 4 * sb + k;
-            float x[18];
-            float qx, qy, qz;
-            qof(jj, qx, qy, qz);
-            joint_values_q<true>(qx, qy, qz, tau, cutb[jj], x);
-            lo[2 * k] = x[16];
-            lo[2 * k + 1] = x[17];
-            mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k, Op<V>::cvt(x));
-            mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 2 * k + 1, Op<V>::cvt(x + 8));
-        }
-        mma_row<V, NT, T, PG_ASYNC_X>(acc, p, st, sb * 9 + 8, Op<V>::cvt(lo));
-    }
-}
-
-// ReLU on packed 16-bit floats: a negative bf16/fp16 is a negative int16, so max_i16(x, 0)
-// clears exactly the negative lanes (v_pk_max_i16: one VALU op per two channels; fmaxf on the
-// fp32 accumulators costs two each because hipcc canonicalises MFMA results first).
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// One asm statement per fragment; the trailing s_nop 1 provides the two wait states a VALU
-// write needs before an MFMA may read the register (hipcc pads nothing for inline asm).
-template <typename V>
-__device__ __forceinline__ V relu16(V v) {
-    const u32x4 w = __builtin_bit_cast(u32x4, v);
-    unsigned r0, r1, r2, r3;
-    asm("v_pk_max_i16 %0, %4, 0\n\tv_pk_max_i16 %1, %5, 0\n\tv_pk_max_i16 %2, %6, 0\n\tv_pk_max_i16 %3, %7, 0\n\ts_nop 1"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)      // early-clobber: outputs are written
-        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));      // before the later inputs are read
-    const u32x4 o = {r0, r1, r2, r3};
-    return __builtin_bit_cast(V, o);
-}
-
-template <typename V>
-__device__ __forceinline__ void relu_pack(const f32x16& acc, V& f0, V& f1, bool relu) {
-    float t[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = acc[r];
-    f0 = Op<V>::cvt(t);
-    f1 = Op<V>::cvt(t + 8);
-    if (relu) { f0 = relu16<V>(f0); f1 = relu16<V>(f1); }
-}
-
-// acc += W[tile o] * fin over the HU hidden units; out-tile-major segment starting at cbase
-template <typename V, int T, bool ASYNC, int NS, typename ST>
-__device__ __forceinline__ void row_tile(f32x16& acc, APipe<V, NS>& p, ST& st, int o, const V* fin) {
-#pragma unroll
-    for (int u = 0; u < HU; ++u) acc = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, o * HU + u), fin[u], acc);
-}
-
-// fout = relu(W fin + b), out-tile-major segment starting at chunk cbase.
-// The ReLU + 16-bit packing of tile o-1 (VALU, needs that tile's last MFMA to retire) is placed
-// after the first MFMAs of tile o, so it runs under them instead of draining the MFMA pipe.
-template <typename V, typename ST>
-__device__ __forceinline__ void hidden_layer(const V* fin, V* fout, ST& st, int cbase,
-                                             const float* bias, int tile0, int h) {
-    APipe<V> p;
-    f32x16 prev, nextb = load_bias(bias, tile0, h);
-#pragma unroll
-    for (int o = 0; o < NT; ++o) {
-        f32x16 acc = nextb;
-        constexpr int T = HU * NT;
-#pragma unroll
-        for (int u = 0; u < HU; ++u) {
-            acc = Op<V>::mfma(next_a<V, T, true, PG_PIPE_H>(p, st, o * HU + u), fin[u], acc);
-            if (u == PG_RELU_AT && o > 0) {
-                // pinned: hoisted to the tile boundary the conversions wait out the last MFMA
-                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
-                relu_pack<V>(prev, fout[2 * (o - 1)], fout[2 * (o - 1) + 1], true);
-                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
-            }
-            // the next tile's bias is read mid-tile (the volatile ring reads pin it here), not at
-            // the boundary where the first MFMA would wait out the LDS latency
-            if (PG_PIN_TILE && u == PG_BIAS_AT && o + 1 < NT) nextb = load_bias(bias, tile0 + o + 1, h);
-        }
-        if (!PG_PIN_TILE && o + 1 < NT) nextb = load_bias(bias, tile0 + o + 1, h);
-        prev = acc;
-    }
-    relu_pack<V>(prev, fout[2 * (NT - 1)], fout[2 * (NT - 1) + 1], true);
-}
-
-// debug: write a fragment array (H-sequence order) as floats to dbg[pt][256]
-template <typename V, int NF>
-__device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long long gp, bool valid, const V* f, int h) {
-    if (a.dbg && a.dbg_stage == stage && valid) {
-#pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a.dbg[gp * W + hseq_channel(8 * u + j, h)] = (float)f[u][j];
-    }
-}
-
-
-// ===================== factorised view layer (pg_layout.h) ===============================
-constexpr int LDS_TOTAL_F = LDS_RTAB + MAXR_F * SLOTF_BYTES;
-static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view layer)");
-
-// Per-ray slots of the factorised path, one thread per (ray, joint):
-//   AB[j] = (a = R_j o + t_j, b = R_j d)                      (core/encoders.py:8-37)
-//   T16[j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(b), rows e, sin e,
-//   cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:172-193) as 16-bit MFMA
-//   operands, zero padded to 32; joint JC = the ray's frame code.
-template <typename V, bool FC, int NTHREADS>
-__device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
-    constexpr int NJ = J + (FC ? 1 : 0);
-    for (int idx = threadIdx.x; idx < nr * NJ; idx += NTHREADS) {
-        const int rr = idx / NJ, j = idx - rr * NJ;
-        uint8_t* slot = rt + rr * SLOTF_BYTES;
-        float t[TK];
-#pragma unroll
-        for (int k = 0; k < TK; ++k) t[k] = 0.0f;
-        if (j < J) {
-            const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
-            const float4 ra = sk[0], rb = sk[1], rc = sk[2];
-            const float* ry = a.rays + (long long)(r0 + rr) * 11;
-            const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
-            float e[3];
-            e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
-            e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
-            e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
-            float4* ab = reinterpret_cast<float4*>(slot + SLOTF_AB + j * 32);
-            ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
-                                fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
-                                fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
-            ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
-            const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float ev = e[c] * inv;
-                const float rev = ev * 0.15915494309189535f;
-                float sn = __builtin_amdgcn_sinf(rev), co = __builtin_amdgcn_cosf(rev);
-                t[c * ROWS_D] = ev;
-#pragma unroll
-                for (int f = 0; f < LD; ++f) {
-                    t[c * ROWS_D + 1 + 2 * f] = sn;
-                    t[c * ROWS_D + 2 + 2 * f] = co;
-                    const float s2 = 2.0f * sn * co;
-                    co = (co - sn) * (co + sn);
-                    sn = s2;
-                }
-            }
-        } else {
-            const float cf = a.cams ? a.cams[r0 + rr] : -1.0f;
-            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
-#pragma unroll
-            for (int k = 0; k < FC_CH; ++k) t[k] = a.codes[ci * FC_CH + k];
-        }
-        V* dst = reinterpret_cast<V*>(slot + SLOTF_T16 + j * (TK * 2));
-#pragma unroll
-        for (int q = 0; q < TK / 8; ++q) dst[q] = Op<V>::cvt(t + 8 * q);
-    }
-}
-
-// Y stage: Y[ray][j][o] for the rays of this pass.  Wave w: out tile w&3, the 12 (13 with the
-// frame code) joints of half w>>2; per joint two K=16 MFMAs with A = T16 (rows = rays) and
-// B = the wave's own weight units (pack_vy), read straight from L2 into registers at the top of
-// the pass (no other wave needs them, so they do not go through the LDS ring).  C has the out
-// channel on the lane and rays 0..3 (lanes < 32) / 4..7 in registers 0..3; joint e of the wave
-// lands in 16-bit slot e%8 of the 16 bytes lane (h, o) of the second stage's A fragment
-// (tile, e/8) holds.
-template <typename V, bool FC>
-struct YWeights {
-    static constexpr int NU = pgp::AF::VY_UNITS(FC);
-    uint4 b[NU];
-    __device__ __forceinline__ void load(const EvalArgs& a, int wave, int lane) {
-        const uint4* p = reinterpret_cast<const uint4*>(a.wy) + ((size_t)wave * NU) * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < NU; ++n) b[n] = p[n * 64];
-    }
-};
-
-template <typename V, bool FC>
-__device__ __forceinline__ void y_stage(const YWeights<V, FC>& yw, uint8_t* rt, int nr, int wave, int lane) {
-    constexpr int NE = JH + (FC ? 1 : 0);
-    using E = typename Op<V>::E;
-    const int t = wave & 3, hw = wave >> 2, hl = lane >> 5, col = lane & 31;
-    const uint8_t* trow = rt + min(col, nr - 1) * SLOTF_BYTES + SLOTF_T16 + hl * 16;
-    const uint8_t* trow_h = trow + hw * (JH * TK * 2);
-    uint8_t* ybase = rt + SLOTF_Y + ((t * 2) * 64 + 32 * hw + col) * 16 + 4 * hl * SLOTF_BYTES;
-#pragma clang loop unroll(full)
-    for (int e = 0; e < NE; ++e) {
-        const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
-        const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj));
-        const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj + 32));
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = Op<V>::mfma(a0, __builtin_bit_cast(V, yw.b[2 * e]), acc);
-        acc = Op<V>::mfma(a1, __builtin_bit_cast(V, yw.b[2 * e + 1]), acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)        // ray = r + 4 hl; only MAXR_F = 5 slots exist
-            if (hl == 0 || r == 0)
-                *reinterpret_cast<E*>(ybase + r * SLOTF_BYTES + (e / 8) * 1024 + (e % 8) * 2) = (E)acc[r];
-    }
-}
-
-// second stage: acc[t] += sum_j w_j Y[ray][j][32t..] for the (at most two) rays of the wave
-template <typename V, bool FC>
-__device__ __forceinline__ void y_apply(f32x16* acc, const uint8_t* rt, const float* wd, int myr, int lane) {
-    const int h = lane >> 5;
-    float wx[16];
-#pragma unroll
-    for (int e = 0; e < JH; ++e) wx[e] = wd[e];
-    wx[12] = (FC && h == 0) ? 1.0f : 0.0f;
-    wx[13] = wx[14] = wx[15] = 0.0f;
-    const u32x4 w0 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx));
-    const u32x4 w1 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx + 8));
-    const int ra = __builtin_amdgcn_readfirstlane(myr);
-    const int rb = __builtin_amdgcn_readlane(myr, 63);
-    for (int ray = ra; ray <= rb; ++ray) {
-        const bool mine = myr == ray;
-        u32x4 b0, b1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { b0[q] = mine ? w0[q] : 0u; b1[q] = mine ? w1[q] : 0u; }
-        const uint8_t* yb = rt + ray * SLOTF_BYTES + SLOTF_Y + lane * 16;
-#pragma unroll
-        for (int t = 0; t < NTV; ++t) {
-            const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2) * 1024));
-            const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2 + 1) * 1024));
-            acc[t] = Op<V>::mfma(a0, __builtin_bit_cast(V, b0), acc[t]);
-            acc[t] = Op<V>::mfma(a1, __builtin_bit_cast(V, b1), acc[t]);
-        }
-    }
-}
-
-#if defined(PG_STAMPS)
-#define PG_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; } while (0)
-#else
-#define PG_STAMP(k) do {} while (0)
-#endif
 
 template <typename V, bool FC, bool FACT>
 __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {

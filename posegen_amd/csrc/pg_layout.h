@@ -140,6 +140,43 @@ PG_HD constexpr int vy_slot_joint(int u, int h, int e, bool fc) {
     return (fc && h == 0 && e == 4) ? JC : -1;
 }
 
+// ---- "small tile" layout of pg_eval16s.hip (v_mfma_f32_16x16x32, factorised view layer) ----
+// A = weights 16 out channels x 32 k, B = activations 32 k x 16 points, C = 16 x 16: lane
+// (g = lane>>4, col = lane&15) holds rows 4g..4g+3.  A wave still owns 32 points = two column
+// tiles c (points 16c + col), every A fragment feeding both; k-unit u of the next layer is
+// out tiles 2u (values 0..3) and 2u+1 (values 4..7) of lane group g.
+constexpr int G16 = 4;                  // lane groups
+constexpr int JG = J / G16;             // 6 joints per lane group
+constexpr int NT16 = W / 16;            // 16 out tiles of the trunk
+constexpr int NTV16 = VW / 16;          // 8 of the view layer
+constexpr int HU16 = W / 32;            // 8 k-units of a trunk activation
+constexpr int XU16 = 14;                // k-units of the density input: 6 joints x 18 = 108 -> 112
+constexpr int XSEQ16 = XU16 * 8;
+PG_HD constexpr int hseq16_channel(int i, int g) { return 16 * (2 * (i / 8) + ((i % 8) >> 2)) + 4 * g + (i & 3); }
+// density-input column of X16-sequence index i of lane group g, in generation order: joints
+// 0..3 (units 0..7: values 0..15), unit 8 = their values 16, 17; joints 4, 5 (units 9..12),
+// unit 13 = their values 16, 17 and 4 zero pads
+PG_HD constexpr int xseq16_channel(int i, int g) {
+    int u = i / 8, e = i % 8, jj = 0, q = 0;
+    if (u < 8) { jj = u / 2; q = 8 * (u % 2) + e; }
+    else if (u == 8) { jj = e / 2; q = 16 + e % 2; }
+    else if (u < 13) { jj = 4 + (u - 9) / 2; q = 8 * ((u - 9) % 2) + e; }
+    else { if (e >= 4) return -1; jj = 4 + e / 2; q = 16 + e % 2; }
+    int j = JG * g + jj;
+    return q < ROWS_V ? q * J + j : CH_V + 3 * j + (q - ROWS_V);
+}
+// second stage of the factorised view layer: joint in slot e of lane group g (-1 = zero)
+PG_HD constexpr int vy16_slot_joint(int g, int e, bool fc) {
+    return e < JG ? JG * g + e : ((fc && g == 0 && e == JG) ? JC : -1);
+}
+// bias tiles of 16 rows, [tile][g][4]: L0..L7 (16 each), alpha, folded view (8), rgb
+constexpr int BS_LAYER0 = 0;
+constexpr int BS_ALPHA = 128;
+constexpr int BS_VIEWF = 129;
+constexpr int BS_RGB = 137;
+constexpr int BS_COUNT = 138;
+constexpr int BIAS16_FLOATS = BS_COUNT * 16;
+
 // bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1), folded view (4)
 constexpr int BT_LAYER0 = 0;
 constexpr int BT_FEAT = 64;

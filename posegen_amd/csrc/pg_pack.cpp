@@ -194,6 +194,63 @@ int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& o
     return 0;
 }
 
+// ---- 16x16x32 kernel: units are 16 out rows x 32 k; lane (g, row) holds k = 32u + 8g + 0..7 ----
+int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
+    if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
+    if (t.viewf_w.size() != (size_t)VW * W) return -4;
+    const bool is_bf = precision == PG_PREC_BF16;
+    struct Seg { int mat, no, nu; bool kmajor, xseq; int colbase; };
+    std::vector<Seg> prog;
+    prog.push_back({MAT_L0, NT16, XU16, true, true, 0});
+    for (int l = 1; l <= 4; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0});
+    prog.push_back({MAT_L0 + 5, NT16, HU16, false, false, CH_X});
+    prog.push_back({MAT_L0 + 5, NT16, XU16, true, true, 0});
+    for (int l = 6; l <= 7; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0});
+    prog.push_back({MAT_ALPHA_VIEWF, NTV16 + 1, HU16, false, false, 0});
+    prog.push_back({MAT_RGB, 1, VW / 32, false, false, 0});
+    out.clear();
+    for (const Seg& sg : prog) {
+        for (int L = 0; L < sg.nu * sg.no; ++L) {
+            const int u = sg.kmajor ? L / sg.no : L % sg.nu;
+            const int o = sg.kmajor ? L % sg.no : L / sg.nu;
+            const size_t base = out.size();
+            out.resize(base + UNIT_BYTES, 0);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, row = lane & 15;
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = sg.xseq ? xseq16_channel(8 * u + e, g) : hseq16_channel(8 * u + e, g);
+                    if (ch < 0) continue;
+                    // MAT_ALPHA_VIEWF keeps its 32-row tile 0 for alpha: rows of 16-tile o are
+                    // alpha (o = 0, row 0) or folded-view row 16 (o - 1) + row
+                    const int wrow = sg.mat == MAT_ALPHA_VIEWF ? (o == 0 ? row : 32 + 16 * (o - 1) + row) : 16 * o + row;
+                    if (sg.mat == MAT_ALPHA_VIEWF && o == 0 && row > 0) continue;
+                    const float wv = t.w(sg.mat, wrow, sg.colbase + ch);
+                    const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
+                    std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                }
+            }
+        }
+        out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
+    }
+    return out.size() == (size_t)S::NCHUNK * CHUNK_BYTES ? 0 : -2;
+}
+
+void pack_bias_s(const NetTensors& t, std::vector<float>& out) {
+    out.assign(BIAS16_FLOATS, 0.f);
+    auto put = [&](int tile, const float* b, int n, int row0) {
+        for (int g = 0; g < G16; ++g)
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * g + r;
+                out[(size_t)tile * 16 + 4 * g + r] = (b && row < n) ? b[row] : 0.f;
+            }
+    };
+    for (int l = 0; l < DEPTH; ++l)
+        for (int o = 0; o < NT16; ++o) put(BS_LAYER0 + l * NT16 + o, t.lb[l], W, 16 * o);
+    put(BS_ALPHA, t.alpha_b, 1, 0);
+    for (int o = 0; o < NTV16; ++o) put(BS_VIEWF + o, t.viewf_b.data(), VW, 16 * o);
+    put(BS_RGB, t.rgb_b, 3, 0);
+}
+
 void pack_bias(const NetTensors& t, std::vector<float>& out) {
     out.assign(BIAS_FLOATS, 0.f);
     auto put = [&](int tile, const float* b, int n, int row0) {

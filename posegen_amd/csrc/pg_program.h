@@ -62,6 +62,18 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 }
 }  // namespace AF
 
+// ---------------- shape S: 16x16x32 tiles, factorised view layer (pg_eval16s.hip) -----
+// [L0 k-major][L1..4][L5h][L5x k-major][L6][L7][alpha | folded view: 9 tiles][rgb]
+namespace S {
+constexpr int UPC = CHUNK_BYTES / UNIT_BYTES;
+constexpr int CH_L0X = cdiv(XU16 * NT16, UPC);          // 7
+constexpr int CH_HID = cdiv(HU16 * NT16, UPC);          // 4
+constexpr int CH_AV = cdiv(HU16 * (NTV16 + 1), UPC);    // 3
+constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AV + 1;
+// 16x16x32 MFMAs per 32-point group (two per unit), without the Y stage (those are 32x32x16)
+constexpr int MFMA_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + HU16 * (NTV16 + 1) + VW / 32) + 2 * NTV16;
+}  // namespace S
+
 // ---------------- shape B: fp32 (UE 4, 1-KiB units) or split 16-bit (UE 8, 2-KiB) ---
 // bytes per sequence position per out tile are the same for both (256 B), so are the chunk counts
 namespace B {

@@ -6,10 +6,10 @@ spill of a register whose load has not landed would read garbage).
 usage: audit_asm_loads.py kernel.s"""
 import re, sys
 txt = open(sys.argv[1]).read()
-kernels = re.split(r'\n(?=_ZN3pgd13eval16_kernel)', txt)
+kernels = re.split(r'\n(?=_ZN3pgd\d+eval16s?_kernel)', txt)
 bad = 0
 for k in kernels:
-    if not k.startswith('_ZN3pgd13eval16_kernel'):
+    if not re.match(r'_ZN3pgd\d+eval16s?_kernel', k):
         continue
     name = k.split(':', 1)[0]
     lines = k.split('\n')
