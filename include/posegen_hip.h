@@ -193,7 +193,8 @@ int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_t
                      int precision, uint8_t* out, int64_t cap, int64_t* out_bytes);
 
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
- * MFMA instructions one 32-point group issues, for the given precision. */
+ * MFMA instructions one 32-point group issues, for the given precision (16-bit precisions:
+ * of the factorised-view program used when a ray has >= 64 samples). */
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group);
 
 #ifdef __cplusplus

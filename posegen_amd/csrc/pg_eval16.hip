@@ -8,11 +8,13 @@
 // Workgroup = 8 waves (2 per SIMD), each wave owns 32 consecutive points of the
 // flattened [ray][sample] list and keeps their activations in registers across all
 // layers (pg_layout.h).  All 8 waves consume the same weight stream, staged
-// L2 -> LDS in 16-KiB chunks by global_load_lds_dwordx4 into a 2-slot ring (chunk c+1
-// in flight while chunk c feeds v_mfma_f32_32x32x16).  The 432-wide density input is
-// produced on the fly as B fragments (never stored) and recomputed for the skip layer;
-// the 648-wide view input is a per-ray sin/cos table in LDS times the per-point cutoff
-// weight.
+// L2 -> LDS in 32-KiB chunks by global_load_lds_dwordx4 into a 3-slot ring (two chunks
+// in flight while one feeds v_mfma_f32_32x32x16).  The 432-wide density input is
+// produced on the fly as B fragments (never stored) and recomputed for the skip layer.
+// The 648-wide view input is either a per-ray sin/cos table in LDS times the per-point
+// cutoff weight (FACT = false, rays with < 64 samples) or factorised over rays
+// (FACT = true: per-ray Y stage + a K=16 contraction over the joints, pg_layout.h);
+// feature_linear is folded into the view layer by the host packer.
 #include "pg_eval16_common.h"
 
 namespace pgd {
