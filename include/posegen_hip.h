@@ -145,6 +145,24 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
                    const float* cyls, int64_t cyl_stride, const float* cams,
                    int n_samples, int n_importance, int flags, const pg_outputs* out);
 
+/* One frame with its front and back end on the device.  Replaces, per
+ * frame: get_rays + the bounding-box gather of kp_to_valid_rays (core/utils/ray_utils.py:6-28,
+ * 83-136), render()'s ray_batch packing (core/trainer.py:118-137), RayCaster.forward on the
+ * box's rays, and render_path's scatter into the background frame (run_nerf.py:98-137) --
+ * no per-frame meshgrid, no host->device copy of rays, no device->host copy of ray maps.
+ *   c2w         HOST [3,4] row-major camera-to-world (12 floats)
+ *   intrinsics  HOST (fx, fy, cx, cy)
+ *   box         HOST (tl_x, tl_y, br_x, br_y) of cylinder_to_box_2d (skeleton_utils.py:711-787),
+ *               br row/column excluded like the reference's torch.arange(tl, br)
+ *   skts [24,4,4], cyl [5] device (one pose per frame); cam: frame-code index (< 0: mean code)
+ *   bg          device [H*W,3] background or NULL for the constant base_bg (1 = white_bkgd)
+ *   rgb [H*W,3], disp [H*W] (NaN of empty rays -> 0), acc [H*W] device outputs (disp, acc may
+ *   be NULL); rgb8 [H*W,3] optional uint8 frame = trunc(clamp(rgb*255)) (run_gan.py:2327). */
+int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
+                    const int* box, float near, float far, const float* skts, const float* cyl, float cam,
+                    int n_samples, int n_importance, int flags, const float* bg, float base_bg,
+                    float* rgb, float* disp, float* acc, uint8_t* rgb8);
+
 /* ---- stage entry points (same kernels, exposed for parity tests and profiling) ---- */
 
 /* get_near_far_in_cylinder + sample_from_lineseg (ray_utils.py:204-251, 292-344). */

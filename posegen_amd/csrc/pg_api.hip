@@ -30,6 +30,20 @@ int pg_launch_composite(const float* rays, const float* z, const float* raw, lon
 int pg_composite_max_samples(void);
 int pg_composite_max_importance(void);
 }
+namespace pgk {
+struct FrameGeom {
+    int H, W, tlx, tly, bw, bh;
+    float fx, fy, cx, cy;
+    float R[9], t[3];
+    float near, far, cam;
+};
+}
+extern "C" {
+int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream);
+int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map, const float* acc_map,
+                            const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8,
+                            void* stream);
+}
 
 namespace {
 
@@ -65,6 +79,8 @@ struct pg_handle {
     float* d_cut = nullptr;
     uint8_t* ws = nullptr;
     size_t ws_bytes = 0;
+    uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
+    size_t fws_bytes = 0;
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
@@ -298,6 +314,7 @@ void pg_destroy(pg_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->fws) (void)hipFree(h->fws);
     for (NetState& ns : h->net) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
@@ -587,6 +604,57 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
     if (out->raw_coarse) PG_HIP(h, hipMemcpyAsync(out->raw_coarse, rawc, (size_t)n * S * 16, hipMemcpyDeviceToDevice, s));
     if (hier && out->z_fine) PG_HIP(h, hipMemcpyAsync(out->z_fine, zf, (size_t)n * SF * 4, hipMemcpyDeviceToDevice, s));
     if (hier && out->raw_fine) PG_HIP(h, hipMemcpyAsync(out->raw_fine, rawf, (size_t)n * SF * 16, hipMemcpyDeviceToDevice, s));
+    return PG_OK;
+}
+
+int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
+                    const int* box, float near, float far, const float* skts, const float* cyl, float cam,
+                    int n_samples, int n_importance, int flags, const float* bg, float base_bg,
+                    float* rgb, float* disp, float* acc, uint8_t* rgb8) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (H <= 0 || W <= 0 || !c2w || !intrinsics || !box || !skts || !cyl || !rgb)
+        return fail(h, PG_EINVAL, "pg_render_frame: null/non-positive argument");
+    pgk::FrameGeom g{};
+    g.H = H; g.W = W;
+    g.tlx = box[0] < 0 ? 0 : box[0]; g.tly = box[1] < 0 ? 0 : box[1];
+    const int brx = box[2] > W ? W : box[2], bry = box[3] > H ? H : box[3];
+    g.bw = brx > g.tlx ? brx - g.tlx : 0; g.bh = bry > g.tly ? bry - g.tly : 0;
+    g.fx = intrinsics[0]; g.fy = intrinsics[1]; g.cx = intrinsics[2]; g.cy = intrinsics[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) g.R[3 * r + c] = c2w[4 * r + c];
+        g.t[r] = c2w[4 * r + 3];
+    }
+    g.near = near; g.far = far; g.cam = cam;
+    const int64_t n = (int64_t)g.bw * g.bh;
+    PG_HIP(h, hipSetDevice(h->device));
+    auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t b_rays = al((size_t)n * 44), b_cam = al((size_t)n * 4), b_rgb = al((size_t)n * 12), b_1 = al((size_t)n * 4);
+    const size_t need = b_rays + b_cam + 2 * b_rgb + 4 * b_1;
+    if (need > h->fws_bytes) {
+        if (h->fws) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->fws)); h->fws = nullptr; h->fws_bytes = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->fws), need + need / 8);
+        if (e != hipSuccess) return fail(h, PG_ENOMEM, "frame workspace allocation of %zu bytes failed", need);
+        h->fws_bytes = need + need / 8;
+    }
+    uint8_t* p = h->fws;
+    float* rays = reinterpret_cast<float*>(p); p += b_rays;
+    float* cams = reinterpret_cast<float*>(p); p += b_cam;
+    pg_outputs out{};
+    out.rgb_map = reinterpret_cast<float*>(p); p += b_rgb;
+    out.rgb0 = reinterpret_cast<float*>(p); p += b_rgb;
+    out.disp_map = reinterpret_cast<float*>(p); p += b_1;
+    out.acc_map = reinterpret_cast<float*>(p); p += b_1;
+    out.disp0 = reinterpret_cast<float*>(p); p += b_1;
+    out.acc0 = reinterpret_cast<float*>(p);
+    const bool fc = h->cfg.framecode_ch > 0;
+    if (n > 0) {
+        int e = pg_launch_frame_rays(&g, rays, fc ? cams : nullptr, stream);
+        if (e) return fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        int rc = pg_render_rays(h, stream, n, rays, skts, 0, cyl, 0, fc ? cams : nullptr, n_samples, n_importance, flags, &out);
+        if (rc) return rc;
+    }
+    int e = pg_launch_frame_compose(&g, out.rgb_map, out.disp_map, out.acc_map, bg, base_bg, rgb, disp, acc, rgb8, stream);
+    if (e) return fail(h, PG_EHIP, "frame compose kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 

@@ -294,6 +294,94 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
 
 }  // namespace pgk
 
+namespace pgk {
+
+// ---- frame front / back end ---------------------------------------
+struct FrameGeom {
+    int H, W, tlx, tly, bw, bh;        // box = pixels [tly, tly+bh) x [tlx, tlx+bw)
+    float fx, fy, cx, cy;
+    float R[9], t[3];                   // c2w[:3,:3] row-major, c2w[:3,3]
+    float near, far, cam;
+};
+
+// ray_batch rows of the box's pixels (get_rays + the bbox gather of kp_to_valid_rays,
+// core/utils/ray_utils.py:6-28, 83-136, and the packing of trainer.py:118-137), in the
+// reference's row-major pixel order.  Plain fp32 ops in the reference's order, no FMA.
+__global__ __launch_bounds__(256) void frame_rays_kernel(const FrameGeom g, float* __restrict__ rays,
+                                                        float* __restrict__ cams) {
+    const long long n = (long long)g.bw * g.bh;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = g.tly + (int)(i / g.bw), c = g.tlx + (int)(i % g.bw);
+        const float dx = __fdiv_rn(__fsub_rn((float)c, g.cx), g.fx);
+        const float dy = -__fdiv_rn(__fsub_rn((float)r, g.cy), g.fy);
+        const float dz = -1.0f;
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            d[k] = __fadd_rn(__fadd_rn(__fmul_rn(dx, g.R[3 * k]), __fmul_rn(dy, g.R[3 * k + 1])), __fmul_rn(dz, g.R[3 * k + 2]));
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        float* o = rays + i * 11;
+        o[0] = g.t[0]; o[1] = g.t[1]; o[2] = g.t[2];
+        o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
+        o[6] = g.near; o[7] = g.far;
+        o[8] = d[0] * inv; o[9] = d[1] * inv; o[10] = d[2] * inv;      // carried, unused (SURVEY a-5)
+        if (cams) cams[i] = g.cam;
+    }
+}
+
+// Scatter of the rendered box into the frame over the background (run_nerf.py:98-137):
+// rgb = rgb_map + (1 - acc) bg, NaN disparity of empty rays -> 0, optional uint8 frame.
+__global__ __launch_bounds__(256) void frame_compose_kernel(const FrameGeom g, const float* __restrict__ rgb_map,
+                                                           const float* __restrict__ disp_map,
+                                                           const float* __restrict__ acc_map,
+                                                           const float* __restrict__ bg, float base_bg,
+                                                           float* __restrict__ rgb, float* __restrict__ disp,
+                                                           float* __restrict__ acc, uint8_t* __restrict__ rgb8) {
+    const long long hw = (long long)g.H * g.W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(p / g.W), c = (int)(p % g.W);
+        float b[3] = {base_bg, base_bg, base_bg};
+        if (bg) { b[0] = bg[p * 3]; b[1] = bg[p * 3 + 1]; b[2] = bg[p * 3 + 2]; }
+        float o[3] = {b[0], b[1], b[2]}, dsp = 0.0f, a = 0.0f;
+        if (r >= g.tly && r < g.tly + g.bh && c >= g.tlx && c < g.tlx + g.bw) {
+            const long long i = (long long)(r - g.tly) * g.bw + (c - g.tlx);
+            a = acc_map[i];
+            dsp = disp_map[i];
+            if (dsp != dsp) dsp = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = __fadd_rn(rgb_map[i * 3 + k], __fmul_rn(__fsub_rn(1.0f, a), b[k]));
+        }
+        rgb[p * 3] = o[0]; rgb[p * 3 + 1] = o[1]; rgb[p * 3 + 2] = o[2];
+        if (disp) disp[p] = dsp;
+        if (acc) acc[p] = a;
+        if (rgb8) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rgb8[p * 3 + k] = (uint8_t)fminf(fmaxf(o[k] * 255.0f, 0.0f), 255.0f);
+        }
+    }
+}
+
+}  // namespace pgk
+
+extern "C" int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream) {
+    const long long n = (long long)g->bw * g->bh;
+    if (n <= 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pgk::frame_rays_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *g, rays, cams);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map,
+                                       const float* acc_map, const float* bg, float base_bg, float* rgb, float* disp,
+                                       float* acc, uint8_t* rgb8, void* stream) {
+    const long long hw = (long long)g->H * g->W;
+    if (hw <= 0) return 0;
+    const unsigned blocks = (unsigned)((hw + 255) / 256 < 4096 ? (hw + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pgk::frame_compose_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *g,
+                       rgb_map, disp_map, acc_map, bg, base_bg, rgb, disp, acc, rgb8);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride,
                                        long long n, int chunk, int S, int lindisp,
                                        float* near_far, float* z, void* stream) {

@@ -204,6 +204,38 @@ class HipRenderer:
             out["extras"] = ex
         return out
 
+    def render_frame(self, H: int, W: int, focal, c2w, box, skts: torch.Tensor, cyl: torch.Tensor,
+                     center=None, cam: Optional[float] = None, near: float = 0., far: float = 1.,
+                     n_samples: Optional[int] = None, n_importance: Optional[int] = None, lindisp: bool = False,
+                     bg: Optional[torch.Tensor] = None, base_bg: float = 0., want_uint8: bool = False):
+        """One frame entirely on the device (pg_render_frame): rays of the pixels in `box` =
+        ((tl_x, tl_y), (br_x, br_y)), render, scatter over the background.  Returns device
+        tensors rgb [H,W,3], disp [H,W,1], acc [H,W,1] (+ rgb8 uint8 [H,W,3])."""
+        cfg = self.cfg
+        S = cfg.n_samples if n_samples is None else int(n_samples)
+        N = cfg.n_importance if n_importance is None else int(n_importance)
+        f = np.asarray(focal.detach().cpu() if isinstance(focal, torch.Tensor) else focal, dtype=np.float64).reshape(-1)
+        fx, fy = (float(f[0]), float(f[0])) if f.size < 2 else (float(f[0]), float(f[1]))
+        cx, cy = (W * 0.5, H * 0.5) if center is None else (float(center[0]), float(center[1]))
+        c2w_h = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w,
+                                                dtype=np.float32)[:3, :4])
+        (tlx, tly), (brx, bry) = box
+        sk, _ = self._pose_args(skts, 1)
+        cy_t, _ = self._cyl_args(cyl, 1)
+        dev = self.device
+        rgb = torch.empty(H, W, 3, device=dev)
+        disp = torch.empty(H, W, 1, device=dev)
+        acc = torch.empty(H, W, 1, device=dev)
+        rgb8 = torch.empty(H, W, 3, device=dev, dtype=torch.uint8) if want_uint8 else None
+        bgt = None if bg is None else _dev_f32(bg.reshape(H * W, 3), dev)
+        self._check(self.lib.pg_render_frame(
+            self.handle, self._stream(), int(H), int(W), c2w_h.ctypes.data_as(C.POINTER(C.c_float)),
+            (C.c_float * 4)(fx, fy, cx, cy), (C.c_int * 4)(int(tlx), int(tly), int(brx), int(bry)),
+            float(near), float(far), _ptr(sk), _ptr(cy_t), -1.0 if cam is None else float(cam), S, N,
+            _ffi.PG_FLAG_LINDISP if lindisp else 0, _ptr(bgt), float(base_bg), _ptr(rgb), _ptr(disp), _ptr(acc),
+            _ptr(rgb8)))
+        return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
+
     # -- stage entry points (tests / profiling) ---------------------------------------
     def stage_sample_coarse(self, ray_batch, cyls, n_samples, lindisp=False):
         rb = _dev_f32(ray_batch, self.device)

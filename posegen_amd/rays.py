@@ -37,11 +37,10 @@ def get_rays(H, W, focal, c2w, center=None):
     return pixel_rays(rows, cols, H, W, focal, c2w, center)
 
 
-def kp_to_valid_rays(poses, H, W, focal, kps=None, cylinder_params=None, skts=None, centers=None,
-                     ext_scale=0.00035):
-    """Per frame: rays of the pixels inside the projected bounding cylinder's box, their
-    flat pixel ids, the cylinders (float32 tensor [F,5]) and the (tl, br) boxes.
-    The `br` row/column is excluded, like the reference's torch.arange(tl, br)."""
+def kp_to_boxes(poses, H, W, focal, kps=None, cylinder_params=None, centers=None, ext_scale=0.00035):
+    """Per frame: the bounding cylinder (float32 tensor [F,5]), its projected 2-D box (tl, br) and
+    the flat ids of the pixels inside it (`br` row/column excluded, like the reference's
+    torch.arange(tl, br)) -- kp_to_valid_rays without the rays (ray_utils.py:83-136)."""
     if cylinder_params is None:
         assert kps is not None
         cylinder_params = get_kp_bounding_cylinder(kps.detach().cpu().numpy(), ext_scale=ext_scale,
@@ -49,7 +48,7 @@ def kp_to_valid_rays(poses, H, W, focal, kps=None, cylinder_params=None, skts=No
                                                    bot_expand_ratio=1.10, head="-y")
         cylinder_params = torch.tensor(np.asarray(cylinder_params), dtype=torch.float32)
     n_pose = cylinder_params.shape[0] if kps is None else kps.shape[0]
-    rays, valid_idxs, bboxes = [], [], []
+    grids, bboxes = [], []
     for i, c2w in enumerate(poses):
         cyl = cylinder_params[i % n_pose]
         f = focal if isinstance(focal, float) else focal[i]
@@ -63,8 +62,19 @@ def kp_to_valid_rays(poses, H, W, focal, kps=None, cylinder_params=None, skts=No
         cc = torch.arange(int(tl[0]), int(br[0]))
         rows = rr[:, None].expand(len(rr), len(cc)).reshape(-1)
         cols = cc[None, :].expand(len(rr), len(cc)).reshape(-1)
-        ro, rd = pixel_rays(rows, cols, h, w, f, torch.as_tensor(c2w_np), center)
-        rays.append((ro, rd))
-        valid_idxs.append(rows * w + cols)
+        grids.append((rows, cols, h, w, f, c2w_np, center))
         bboxes.append((tl, br))
+    return cylinder_params, bboxes, grids
+
+
+def kp_to_valid_rays(poses, H, W, focal, kps=None, cylinder_params=None, skts=None, centers=None,
+                     ext_scale=0.00035):
+    """Per frame: rays of the pixels inside the projected bounding cylinder's box, their
+    flat pixel ids, the cylinders (float32 tensor [F,5]) and the (tl, br) boxes."""
+    cylinder_params, bboxes, grids = kp_to_boxes(poses, H, W, focal, kps=kps, cylinder_params=cylinder_params,
+                                                 centers=centers, ext_scale=ext_scale)
+    rays, valid_idxs = [], []
+    for rows, cols, h, w, f, c2w_np, center in grids:
+        rays.append(pixel_rays(rows, cols, h, w, f, torch.as_tensor(c2w_np), center))
+        valid_idxs.append(rows * w + cols)
     return rays, valid_idxs, cylinder_params, bboxes

@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .rays import kp_to_valid_rays
+from .rays import kp_to_boxes, kp_to_valid_rays
 
 
 def _caster_device(ray_caster):
@@ -81,37 +81,32 @@ def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, 
     if kp is None and cyls is None:
         raise NotImplementedError("render_path needs kp or cyls (bounding-cylinder cull)")
     r, dev = _caster_device(render_kwargs["ray_caster"])
-    rays, valid_idxs, cyls, bboxes = kp_to_valid_rays(render_poses, H, W, focal, kps=kp, cylinder_params=cyls,
-                                                      skts=skts, ext_scale=ext_scale, centers=centers)
+    # Boxes on the host (float64 numpy like the reference); rays, rendering and the scatter into
+    # the background frame on the device (pg_render_frame): no per-frame meshgrid, no ray copies.
+    cyls, bboxes, grids = kp_to_boxes(render_poses, H, W, focal, kps=kp, cylinder_params=cyls,
+                                      ext_scale=ext_scale, centers=centers)
+    valid_idxs = [rows * w + cols for rows, cols, _, w, _, _, _ in grids]
     ids = list(range(len(render_poses))) if frame_ids is None else list(frame_ids)
     rgbs, disps, accs = [], [], []
-    kw = dict(render_kwargs)
-    kw["want_alpha"] = False                    # render_path reads rgb/disp/acc only (run_nerf.py:98)
+    kw = render_kwargs
+    r.set_chunk(int(chunk))
     for i in ids:
-        h = H if isinstance(H, int) else H[i]
-        w = W if isinstance(W, int) else W[i]
-        ro, rd = rays[i]
+        _, _, h, w, f, c2w_np, center = grids[i]
+        bg = None
         if bg_imgs is not None and not white_bkgd:
             import torch.nn.functional as F
-            bg = torch.tensor(bg_imgs[bg_indices[i]] if bg_indices is not None else bg_imgs[0])
-            rgb_img = F.interpolate(bg.permute(2, 0, 1)[None].float(), size=(h, w), mode="bilinear",
-                                    align_corners=False)[0].permute(1, 2, 0).reshape(h * w, 3).to(dev)
-        else:
-            rgb_img = torch.ones(h * w, 3, device=dev) if white_bkgd else torch.zeros(h * w, 3, device=dev)
-        disp_img = torch.zeros(h * w, device=dev)
-        acc_img = torch.zeros(h * w, device=dev)
-        if len(ro) > 0:
-            ret = render(h, w, focal, rays=(ro, rd), chunk=chunk, kp_batch=_pick(kp, i), skts=_pick(skts, i),
-                         cyls=_pick(cyls, i), cams=_pick(cams, i), subject_idxs=_pick(subject_idxs, i),
-                         bones=_pick(bones, i), **kw)
-            vid = valid_idxs[i].to(dev)
-            acc = ret["acc_map"]
-            rgb_img[vid] = ret["rgb_map"] + (1. - acc[..., None]) * rgb_img[vid]
-            disp_img[vid] = ret["disp_map"]
-            acc_img[vid] = acc
-        rgbs.append(rgb_img.view(h, w, 3))
-        disps.append(disp_img.view(h, w, 1))
-        accs.append(acc_img.view(h, w, 1))
+            bgi = torch.tensor(bg_imgs[bg_indices[i]] if bg_indices is not None else bg_imgs[0])
+            bg = F.interpolate(bgi.permute(2, 0, 1)[None].float(), size=(h, w), mode="bilinear",
+                               align_corners=False)[0].permute(1, 2, 0).reshape(h * w, 3).to(dev)
+        cam = _pick(cams, i)
+        rgb_img, disp_img, acc_img = r.render_frame(
+            h, w, f, c2w_np, bboxes[i], _pick(skts, i), _pick(cyls, i), center=center,
+            cam=None if cam is None else float(torch.as_tensor(cam).reshape(-1)[0]),
+            n_samples=kw.get("N_samples"), n_importance=kw.get("N_importance"), lindisp=bool(kw.get("lindisp", False)),
+            bg=bg, base_bg=1.0 if white_bkgd else 0.0)
+        rgbs.append(rgb_img)
+        disps.append(disp_img)
+        accs.append(acc_img)
     rgbs = torch.stack(rgbs).cpu().numpy()
     disps = torch.stack(disps).cpu().numpy()
     disps[np.isnan(disps)] = 0.

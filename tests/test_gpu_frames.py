@@ -87,3 +87,39 @@ def test_rays_are_independent_of_batching(caster):
     part = r.render_rays(rb[5000:5777], skts, cyl, want_alpha=False)
     for k in ("rgb_map", "disp_map", "acc_map"):
         assert torch.equal(full[k][5000:5777], part[k])
+
+
+def test_render_frame_equals_ray_level_path(caster):
+    """pg_render_frame (rays generated, rendered and scattered on the device) against the
+    ray-level route the reference takes: kp_to_valid_rays on the host -> render() -> scatter."""
+    from posegen_amd.rays import kp_to_valid_rays
+    from posegen_amd.render import render
+    g = load_golden("frame64")
+    cfg = caster.cfg
+    r = caster.renderer
+    r.set_precision(PREC_FP32)
+    r.set_chunk(int(g["chunk"]))
+    H, W = int(g["H"]), int(g["W"])
+    c2ws, kps, skts = torch.tensor(g["c2ws"]), torch.tensor(g["kps"]), torch.tensor(g["skts"])
+    rays, vids, cyls, boxes = kp_to_valid_rays(c2ws, H, W, g["focals"], kps=kps, ext_scale=cfg.ext_scale)
+    kw = {"ray_caster": caster, "perturb": False, "N_importance": cfg.n_importance, "N_samples": cfg.n_samples,
+          "use_viewdirs": True, "raw_noise_std": 0., "ray_noise_std": 0., "ext_scale": cfg.ext_scale,
+          "preproc_kwargs": {}, "lindisp": False, "nerf_type": "nerf", "want_alpha": False}
+    for i in range(len(c2ws)):
+        ret = render(H, W, g["focals"], rays=rays[i], chunk=int(g["chunk"]), kp_batch=kps[i:i + 1],
+                     skts=skts[i:i + 1], cyls=cyls[i:i + 1], cams=None, subject_idxs=None, bones=None, **kw)
+        ref_rgb = torch.ones(H * W, 3, device=DEV)
+        ref_acc = torch.zeros(H * W, device=DEV)
+        vid = vids[i].to(DEV)
+        ref_rgb[vid] = ret["rgb_map"] + (1. - ret["acc_map"][..., None]) * ref_rgb[vid]
+        ref_acc[vid] = ret["acc_map"]
+        rgb, disp, acc, rgb8 = r.render_frame(H, W, g["focals"][i], c2ws[i], boxes[i], skts[i:i + 1], cyls[i:i + 1],
+                                              base_bg=1.0, want_uint8=True)
+        e = float((rgb.view(-1, 3) - ref_rgb).abs().max())
+        print(f"frame {i}: device front/back end vs ray-level route: max |d rgb| {e:.2e}, "
+              f"bitwise {bool(torch.equal(rgb.view(-1, 3), ref_rgb))}")
+        assert e <= 2e-6
+        assert float((acc.view(-1) - ref_acc).abs().max()) <= 2e-6
+        assert torch.isfinite(disp).all()
+        q = (rgb * 255.0).clamp(0, 255).to(torch.uint8)
+        assert torch.equal(rgb8, q)

@@ -113,7 +113,7 @@ for f in range(5):
     assert torch.all(full[f] == f + 1), (rank, f)
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ok_{rank}"), "w").write("ok")
 """
 
 
@@ -131,7 +131,7 @@ def test_gather_frames_gloo_world2(tmp_path):
         if out.returncode == 0 or "address already in use" not in (out.stdout + out.stderr).lower():
             break
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()      # (stdout of the ranks interleaves)
 
 
 def test_inline_asm_ring_reads_are_not_touched_by_the_compiler():
