@@ -163,6 +163,18 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
                     int n_samples, int n_importance, int flags, const float* bg, float base_bg,
                     float* rgb, float* disp, float* acc, uint8_t* rgb8);
 
+/* Batched pose kinematics on the device: replaces get_smpl_l2ws and
+ * the kp / skts derivation of load_retarget (core/utils/skeleton_utils.py:379-463,
+ * run_gan.py:2211-2257) so that generator outputs can stay on the GPU.
+ *   bones     device [n_poses,24,3] float64 axis-angle
+ *   bone_offsets HOST [24,3] float64: rest[0] for the root, rest[j] - rest[parent[j]] otherwise,
+ *             formed by the caller in the rest pose's own dtype as the reference does (float32
+ *             for smpl_rest_pose); parents HOST [24] (joint tree, parent < child)
+ *   kps [n,24,3] f32, skts [n,24,4,4] f32 (= l2w^-1), l2ws [n,24,4,4] f64: device, any may be NULL
+ * float64 arithmetic like the reference; float32 outputs are rounded once. */
+int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double* bones, const double* bone_offsets,
+                       const int32_t* parents, float* kps, float* skts, double* l2ws);
+
 /* ---- stage entry points (same kernels, exposed for parity tests and profiling) ---- */
 
 /* get_near_far_in_cylinder + sample_from_lineseg (ray_utils.py:204-251, 292-344). */

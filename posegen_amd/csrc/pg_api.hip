@@ -40,6 +40,8 @@ struct FrameGeom {
 }
 extern "C" {
 int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream);
+int pg_launch_pose_kinematics(const double* offs72, const int* parents24, const double* bones, long long n,
+                              float* kps, float* skts, double* l2ws, void* stream);
 int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map, const float* acc_map,
                             const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8,
                             void* stream);
@@ -604,6 +606,21 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
     if (out->raw_coarse) PG_HIP(h, hipMemcpyAsync(out->raw_coarse, rawc, (size_t)n * S * 16, hipMemcpyDeviceToDevice, s));
     if (hier && out->z_fine) PG_HIP(h, hipMemcpyAsync(out->z_fine, zf, (size_t)n * SF * 4, hipMemcpyDeviceToDevice, s));
     if (hier && out->raw_fine) PG_HIP(h, hipMemcpyAsync(out->raw_fine, rawf, (size_t)n * SF * 16, hipMemcpyDeviceToDevice, s));
+    return PG_OK;
+}
+
+int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double* bones, const double* bone_offsets,
+                       const int32_t* parents, float* kps, float* skts, double* l2ws) {
+    const double* rest_pose = bone_offsets;
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (n_poses < 0 || !bones || !rest_pose || !parents) return fail(h, PG_EINVAL, "pg_pose_kinematics: null/negative argument");
+    if (h->cfg.n_joints != 24) return fail(h, PG_EINVAL, "pg_pose_kinematics: 24-joint SMPL skeleton only");
+    for (int j = 0; j < 24; ++j)
+        if (parents[j] < 0 || parents[j] > j || (j > 0 && parents[j] == j))
+            return fail(h, PG_EINVAL, "pg_pose_kinematics: joint %d must come after its parent (%d)", j, parents[j]);
+    PG_HIP(h, hipSetDevice(h->device));
+    int e = pg_launch_pose_kinematics(rest_pose, parents, bones, n_poses, kps, skts, l2ws, stream);
+    if (e) return fail(h, PG_EHIP, "pose kinematics kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 

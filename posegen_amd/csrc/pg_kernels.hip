@@ -361,7 +361,75 @@ __global__ __launch_bounds__(256) void frame_compose_kernel(const FrameGeom g, c
     }
 }
 
+// ---- batched pose kinematics --------------------------------------
+// get_smpl_l2ws (core/utils/skeleton_utils.py:379-463; run_gan.py:2211-2257): axis-angle ->
+// rotation (scipy's rotvec -> unit quaternion -> matrix map), chain product down the joint
+// tree, kp = l2w[:3,3], skt = l2w^-1 (rigid: [R^T | -R^T t]).  One thread per pose, all in
+// float64 like the reference; outputs rounded to float32 once, as the reference's tensors are.
+struct PoseConst { double offs[24 * 3]; int parent[24]; };   // offs[j] = rest[j] - rest[parent[j]] (rest[0] for the root)
+
+__global__ __launch_bounds__(64) void pose_kinematics_kernel(const PoseConst pc, const double* __restrict__ bones,
+                                                             long long n, float* __restrict__ kps,
+                                                             float* __restrict__ skts, double* __restrict__ l2ws_out) {
+    const long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    double l2w[24][12];                       // rows 0..2 of each 4x4
+    for (int j = 0; j < 24; ++j) {
+        const double rx = bones[(f * 24 + j) * 3], ry = bones[(f * 24 + j) * 3 + 1], rz = bones[(f * 24 + j) * 3 + 2];
+        const double t2 = rx * rx + ry * ry + rz * rz, th = sqrt(t2);
+        const double k = th < 1e-3 ? 0.5 - t2 / 48.0 + t2 * t2 / 3840.0 : sin(0.5 * th) / th;
+        double qx = rx * k, qy = ry * k, qz = rz * k, qw = cos(0.5 * th);
+        const double nrm = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+        qx /= nrm; qy /= nrm; qz /= nrm; qw /= nrm;
+        const double xx = qx * qx, yy = qy * qy, zz = qz * qz, ww = qw * qw;
+        const double xy = qx * qy, zw = qz * qw, xz = qx * qz, yw = qy * qw, yz = qy * qz, xw = qx * qw;
+        double rel[12];
+        rel[0] = xx - yy - zz + ww; rel[1] = 2.0 * (xy - zw);    rel[2] = 2.0 * (xz + yw);
+        rel[4] = 2.0 * (xy + zw);   rel[5] = -xx + yy - zz + ww; rel[6] = 2.0 * (yz - xw);
+        rel[8] = 2.0 * (xz - yw);   rel[9] = 2.0 * (yz + xw);    rel[10] = -xx - yy + zz + ww;
+        const int p = pc.parent[j];
+        for (int c = 0; c < 3; ++c) rel[4 * c + 3] = pc.offs[3 * j + c];
+        if (j == 0) {
+            for (int e = 0; e < 12; ++e) l2w[0][e] = rel[e];
+        } else {
+            for (int r = 0; r < 3; ++r) {
+                const double a0 = l2w[p][4 * r], a1 = l2w[p][4 * r + 1], a2 = l2w[p][4 * r + 2], a3 = l2w[p][4 * r + 3];
+                for (int c = 0; c < 4; ++c)
+                    l2w[j][4 * r + c] = a0 * rel[c] + a1 * rel[4 + c] + a2 * rel[8 + c] + (c == 3 ? a3 : 0.0);
+            }
+        }
+    }
+    for (int j = 0; j < 24; ++j) {
+        const double* m = l2w[j];
+        if (kps) for (int c = 0; c < 3; ++c) kps[(f * 24 + j) * 3 + c] = (float)m[4 * c + 3];
+        if (l2ws_out) {
+            for (int e = 0; e < 12; ++e) l2ws_out[(f * 24 + j) * 16 + e] = m[e];
+            l2ws_out[(f * 24 + j) * 16 + 12] = 0.0; l2ws_out[(f * 24 + j) * 16 + 13] = 0.0;
+            l2ws_out[(f * 24 + j) * 16 + 14] = 0.0; l2ws_out[(f * 24 + j) * 16 + 15] = 1.0;
+        }
+        if (skts) {
+            float* o = skts + (f * 24 + j) * 16;
+            for (int r = 0; r < 3; ++r) {
+                o[4 * r] = (float)m[r]; o[4 * r + 1] = (float)m[4 + r]; o[4 * r + 2] = (float)m[8 + r];
+                o[4 * r + 3] = (float)(-(m[r] * m[3] + m[4 + r] * m[7] + m[8 + r] * m[11]));
+            }
+            o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+        }
+    }
+}
+
 }  // namespace pgk
+
+extern "C" int pg_launch_pose_kinematics(const double* offs72, const int* parents24, const double* bones, long long n,
+                                         float* kps, float* skts, double* l2ws, void* stream) {
+    if (n <= 0) return 0;
+    pgk::PoseConst pc;
+    for (int i = 0; i < 72; ++i) pc.offs[i] = offs72[i];
+    for (int i = 0; i < 24; ++i) pc.parent[i] = parents24[i];
+    hipLaunchKernelGGL(pgk::pose_kinematics_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), pc, bones, n, kps, skts, l2ws);
+    return (int)hipGetLastError();
+}
 
 extern "C" int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream) {
     const long long n = (long long)g->bw * g->bh;

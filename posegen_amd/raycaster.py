@@ -236,6 +236,26 @@ class HipRenderer:
             _ptr(rgb8)))
         return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
 
+    def pose_kinematics(self, bones: torch.Tensor, rest_pose, parents=None, want_l2ws: bool = False):
+        """bones [F,24,3] axis-angle (any device/dtype) -> device kps [F,24,3] f32, skts [F,24,4,4] f32
+        (+ l2ws f64), computed on the device in float64 (pg_pose_kinematics; the host equivalent is
+        skeleton.bones_to_pose)."""
+        from .skeleton import SMPLSkeleton
+        b = torch.as_tensor(bones).to(device=self.device, dtype=torch.float64).contiguous()
+        F = b.shape[0]
+        par = np.ascontiguousarray(np.asarray(SMPLSkeleton.joint_trees if parents is None else parents, dtype=np.int32))
+        rp = np.asarray(rest_pose).reshape(24, 3)             # offsets in the rest pose's own dtype, like
+        offs = rp.copy()                                      # get_smpl_l2ws (float32 for smpl_rest_pose)
+        offs[1:] = rp[1:] - rp[par[1:]]
+        rest = np.ascontiguousarray(offs.astype(np.float64))
+        kps = torch.empty(F, 24, 3, device=self.device)
+        skts = torch.empty(F, 24, 4, 4, device=self.device)
+        l2ws = torch.empty(F, 24, 4, 4, device=self.device, dtype=torch.float64) if want_l2ws else None
+        self._check(self.lib.pg_pose_kinematics(self.handle, self._stream(), F, _ptr(b),
+                                                rest.ctypes.data_as(C.POINTER(C.c_double)),
+                                                par.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(kps), _ptr(skts), _ptr(l2ws)))
+        return (kps, skts, l2ws) if want_l2ws else (kps, skts)
+
     # -- stage entry points (tests / profiling) ---------------------------------------
     def stage_sample_coarse(self, ray_batch, cyls, n_samples, lindisp=False):
         rb = _dev_f32(ray_batch, self.device)

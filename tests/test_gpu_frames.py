@@ -123,3 +123,24 @@ def test_render_frame_equals_ray_level_path(caster):
         assert torch.isfinite(disp).all()
         q = (rgb * 255.0).clamp(0, 255).to(torch.uint8)
         assert torch.equal(rgb8, q)
+
+
+def test_pose_kinematics_matches_reference_golden(caster):
+    """pg_pose_kinematics (device, float64) against the reference's get_smpl_l2ws / inverse
+    (golden kinematics fixture) and against the host float64 port on random poses."""
+    from posegen_amd.skeleton import bones_to_pose
+    g = load_golden("kinematics")
+    kps, skts, l2ws = caster.renderer.pose_kinematics(torch.tensor(g["bones"]), g["rest_pose"], want_l2ws=True)
+    assert float(np.abs(l2ws.cpu().numpy() - g["l2ws"]).max()) <= 1e-12
+    assert float(np.abs(kps.cpu().numpy() - g["kps"]).max()) <= 1e-6
+    assert float(np.abs(skts.cpu().numpy() - g["skts"]).max()) <= 1e-6
+    rng = np.random.RandomState(5)
+    bones = rng.normal(0, 0.6, size=(257, 24, 3))
+    bones[0] = 0.0                                   # identity rotations (small-angle branch)
+    bones[1] *= 1e-5
+    rest = g["rest_pose"]
+    k_ref, s_ref, l_ref = bones_to_pose(bones, rest)
+    kps, skts, l2ws = caster.renderer.pose_kinematics(torch.tensor(bones), rest, want_l2ws=True)
+    assert float(np.abs(l2ws.cpu().numpy() - l_ref).max()) <= 1e-12
+    assert np.array_equal(kps.cpu().numpy(), k_ref.astype(np.float32))
+    assert float(np.abs(skts.cpu().numpy() - s_ref).max()) <= 1e-6
