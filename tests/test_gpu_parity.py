@@ -135,6 +135,32 @@ def test_stage_eval_coarse(casters, prec, quant, tol):
     assert dr <= tol * max(1.0, scale / 10)
 
 
+@pytest.mark.parametrize("golden,S", [("rays_surreal", 33), ("rays_surreal", 63), ("rays_surreal", 64),
+                                      ("rays_surreal", 65), ("rays_surreal", 80), ("rays_surreal", 97),
+                                      ("rays_surreal", 200), ("rays_h36m", 64), ("rays_h36m", 85)])
+def test_stage_eval_alignments_fp16_vs_fp32(casters, golden, S):
+    """Sample counts around the switch to the factorised view layer (>= 64) and off every
+    alignment (points not a multiple of a 256-point pass, rays straddling waves and passes,
+    frame codes): the 16-bit kernel against the fp32 kernel, which keeps the direct form."""
+    g = load_golden(golden)
+    cfg = cfg_from_golden(g)
+    rb, skts, cyl, cams = _inputs(g)
+    n = 37
+    rb = rb[:n]
+    cams_n = None if cams is None else cams[:n]
+    rng = np.random.RandomState(S)
+    z0 = torch.tensor(g["z_coarse"][:n])
+    lo, hi = z0[:, :1], z0[:, -1:]
+    z = lo + (hi - lo) * torch.tensor(np.sort(rng.uniform(0, 1, size=(n, S)), axis=1), dtype=torch.float32)
+    ref = casters(cfg, int(g["seed_model"]), PREC_FP32).renderer.stage_eval(0, rb, z, skts, cams=cams_n).cpu()
+    got = casters(cfg, int(g["seed_model"]), PREC_FP16).renderer.stage_eval(0, rb, z, skts, cams=cams_n).cpu()
+    scale = float(ref.abs().max())
+    d = _maxdiff(got.numpy(), ref.numpy())
+    print(f"[{golden} S={S}] fp16 vs fp32 kernel: raw maxdiff {d:.3e} (|raw| max {scale:.1f})")
+    assert torch.isfinite(got).all()
+    assert d <= 1e-2 * max(1.0, scale / 10)
+
+
 @pytest.mark.parametrize("prec", [PREC_FP32, PREC_BF16])
 def test_stage_eval_per_ray_pose_equals_shared(casters, prec):
     """pose_stride = 384 (per-ray skts, as the reference passes them) == shared pose."""
