@@ -144,3 +144,38 @@ def test_pose_kinematics_matches_reference_golden(caster):
     assert float(np.abs(l2ws.cpu().numpy() - l_ref).max()) <= 1e-12
     assert np.array_equal(kps.cpu().numpy(), k_ref.astype(np.float32))
     assert float(np.abs(skts.cpu().numpy() - s_ref).max()) <= 1e-6
+
+
+def test_render_frame_background_image_and_frame_code():
+    """pg_render_frame with a background image and with a per-frame frame code (h36m config),
+    against the ray-level route: same pixels."""
+    from posegen_amd import h36m_config
+    from posegen_amd.raycaster import HipRayCaster
+    from posegen_amd.rays import kp_to_valid_rays
+    cfg = h36m_config()
+    wc, wf, tv, td = syn.make_model(cfg, 2)
+    c = HipRayCaster.from_weights(cfg, wc, wf, tv, td, device=DEV, precision=PREC_FP32)
+    try:
+        r = c.renderer
+        H = W = 48
+        _, kps, skts = syn.make_pose(2, 3)
+        c2ws, focals = syn.make_camera(2, H, W)
+        kps, skts, c2ws = torch.tensor(kps), torch.tensor(skts), torch.tensor(c2ws)
+        rays, vids, cyls, boxes = kp_to_valid_rays(c2ws, H, W, focals, kps=kps, ext_scale=cfg.ext_scale)
+        bg = torch.rand(H * W, 3, generator=torch.Generator().manual_seed(0))
+        for i, cam in ((0, 3.0), (1, -1.0)):
+            ro, rd = rays[i]
+            n = ro.shape[0]
+            assert n > 0
+            vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+            rb = torch.cat([ro, rd, torch.zeros(n, 1), torch.ones(n, 1), vd], -1)
+            ret = r.render_rays(rb, skts[i:i + 1], cyls[i:i + 1], cams=torch.full((n,), cam), want_alpha=False)
+            ref = bg.clone().to(DEV)
+            vid = vids[i].to(DEV)
+            ref[vid] = ret["rgb_map"] + (1. - ret["acc_map"][..., None]) * ref[vid]
+            rgb, disp, acc = r.render_frame(H, W, focals[i], c2ws[i], boxes[i], skts[i:i + 1], cyls[i:i + 1],
+                                            cam=cam, bg=bg)
+            assert torch.equal(rgb.view(-1, 3), ref), f"frame {i}: max diff {float((rgb.view(-1, 3) - ref).abs().max()):.2e}"
+            assert float(acc.max()) > 0.05
+    finally:
+        c.renderer.close()
