@@ -393,3 +393,24 @@ def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PR
     return {"ray_caster": caster, "perturb": False, "N_importance": cfg.n_importance,
             "N_samples": cfg.n_samples, "use_viewdirs": True, "raw_noise_std": 0., "ray_noise_std": 0.,
             "ext_scale": cfg.ext_scale, "preproc_kwargs": {}, "lindisp": cfg.lindisp, "nerf_type": "nerf"}
+
+
+_RAYCASTER_CACHE: Dict[tuple, dict] = {}
+
+
+def load_raycaster(ckpt_path: str, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+    """`create_raycaster` on an A-NeRF checkpoint file (`.tar`, the reference's five state dicts,
+    core/raycasters.py:752-766), memoised on (path, mtime, size, config, device, precision).
+
+    The reference's `run_render` reloads and re-wraps the checkpoint on every call of the GAN
+    loop (run_gan.py:135-165, 2290-2330); here a repeated call returns the caster whose packed
+    weights are already resident on the device."""
+    import os
+    st = os.stat(ckpt_path)
+    key = (os.path.abspath(ckpt_path), st.st_mtime_ns, st.st_size, repr(cfg), str(device), int(precision))
+    kw = _RAYCASTER_CACHE.get(key)
+    if kw is None:
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        kw = create_raycaster(cfg, ckpt, device=device, precision=precision)
+        _RAYCASTER_CACHE[key] = kw
+    return dict(kw)

@@ -179,3 +179,29 @@ def test_render_frame_background_image_and_frame_code():
             assert float(acc.max()) > 0.05
     finally:
         c.renderer.close()
+
+
+def test_checkpoint_round_trip_and_cached_loader(tmp_path):
+    """state_dict() in the reference's five-dict key scheme -> .tar -> load_raycaster: the same
+    renders, and a second load of the unchanged file returns the resident caster."""
+    from posegen_amd import h36m_config
+    from posegen_amd.raycaster import HipRayCaster, load_raycaster
+    from bench import full_frame_rays
+    cfg = h36m_config()
+    wc, wf, tv, td = syn.make_model(cfg, 4)
+    a = HipRayCaster.from_weights(cfg, wc, wf, tv, td, device=DEV, precision=PREC_FP32)
+    path = str(tmp_path / "ckpt.tar")
+    sd = a.state_dict()
+    assert {"network_fn_state_dict", "network_fine_state_dict", "embed_state_dict", "embeddirs_state_dict",
+            "embedbones_state_dict"} <= set(sd)
+    torch.save(sd, path)
+    kw = load_raycaster(path, cfg, device=DEV, precision=PREC_FP32)
+    kw2 = load_raycaster(path, cfg, device=DEV, precision=PREC_FP32)
+    assert kw2["ray_caster"] is kw["ray_caster"]
+    rb, skts, cyl, *_ = full_frame_rays(32, 32, torch.device(DEV))
+    cams = torch.full((rb.shape[0],), 2.0)
+    x = a.renderer.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+    y = kw["ray_caster"].renderer.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+    for k in ("rgb_map", "disp_map", "acc_map"):
+        assert torch.equal(x[k], y[k])
+    a.renderer.close()
