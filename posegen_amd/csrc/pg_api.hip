@@ -18,6 +18,7 @@
 extern "C" {
 int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream);
 int pg_launch_eval16s(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_eval16w(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
@@ -150,6 +151,12 @@ bool use_small_tiles() {
     return on;
 }
 
+// one wave per SIMD x 64 points (pg_eval16w.hip) instead of two x 32: POSEGEN_WAVES=4
+bool use_wide_waves() {
+    static const bool on = [] { const char* e = std::getenv("POSEGEN_WAVES"); return e && std::strcmp(e, "4") == 0; }();
+    return on;
+}
+
 int ensure_stream_s(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (ns.d_stream_s[prec]) return PG_OK;
@@ -255,6 +262,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
     int e = small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
+          : (fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {

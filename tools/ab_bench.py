@@ -5,7 +5,7 @@ libs = sys.argv[1:]
 res = {l: [] for l in libs}
 for rnd in range(3):
     for l in libs:
-        env = dict(os.environ, POSEGEN_HIP_LIB=os.path.abspath(l))
+        env = dict(os.environ, POSEGEN_HIP_LIB=os.path.abspath(l), **{k: v for k, v in (kv.split("=") for kv in os.environ.get("AB_ENV", "").split() if kv)})
         out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-modes"],
                              capture_output=True, text=True, env=env)
         d = json.loads(out.stdout.strip().split("\n")[-1])

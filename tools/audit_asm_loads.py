@@ -6,10 +6,10 @@ spill of a register whose load has not landed would read garbage).
 usage: audit_asm_loads.py kernel.s"""
 import re, sys
 txt = open(sys.argv[1]).read()
-kernels = re.split(r'\n(?=_ZN3pgd\d+eval16s?_kernel)', txt)
+kernels = re.split(r'\n(?=_ZN3pgd\d+eval16[sw]?_kernel)', txt)
 bad = 0
 for k in kernels:
-    if not re.match(r'_ZN3pgd\d+eval16s?_kernel', k):
+    if not re.match(r'_ZN3pgd\d+eval16[sw]?_kernel', k):
         continue
     name = k.split(':', 1)[0]
     lines = k.split('\n')

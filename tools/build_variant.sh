@@ -1,12 +1,18 @@
 #!/bin/bash
 # build_variant.sh NAME [extra hipcc flags...]  -> build_ab/lib_NAME.so
-# (pg_eval16.hip recompiled with the extra flags, other objects from the regular build)
+# (FILE=pg_eval16.hip by default: that source recompiled with the extra flags, other objects
+#  from the regular build)
 set -e
 cd "$(dirname "$0")/../posegen_amd/csrc"
 name=$1; shift
+src=${FILE:-pg_eval16.hip}
+base=${src%.hip}
 mkdir -p ../../build_ab
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -fno-slp-vectorize"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c pg_eval16.hip -o ../../build_ab/eval16_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ab/lib_$name.so ../../build_ab/eval16_$name.o \
-   ../_lib/obj/pg_api.o ../_lib/obj/pg_eval32.o ../_lib/obj/pg_kernels.o ../_lib/obj/pg_pack.o
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ../../build_ab/${base}_$name.o
+objs=""
+for o in pg_api pg_eval16 pg_eval16s pg_eval16w pg_eval32 pg_kernels pg_pack; do
+  if [ "$o" = "$base" ]; then objs="$objs ../../build_ab/${base}_$name.o"; else objs="$objs ../_lib/obj/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ab/lib_$name.so $objs
 echo built build_ab/lib_$name.so
