@@ -1,6 +1,6 @@
 """GPU diagnostic: per-precision error statistics of the fused embed+MLP stage."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import anerf_oracle as orc
 from posegen_amd import PREC_NAMES
