@@ -173,7 +173,7 @@ def main():
     # input is factorised over rays, both exact in real arithmetic.  The MFMA
     # flops actually issued are reported beside it.
     q = r.query()
-    mfma_flop = {"bf16": 32768, "fp16": 32768, "fp32": 4096}.get(a.prec)
+    mfma_flop = {"bf16": 32768, "fp16": 32768, "bf16x3": 32768, "fp32": 4096}.get(a.prec)
     if mfma_flop:
         ex = q["mfma_per_group"] * mfma_flop / 32.0
         result["roofline"]["executed_flop_per_point"] = ex
@@ -206,11 +206,11 @@ def main():
 
     if not a.no_modes and world == 1:
         modes = {}
-        for name in ("fp16", "fp32"):
+        for name in ("fp16", "bf16x3", "fp32"):
             if name == a.prec:
                 continue
             r.set_precision(name)
-            steps = 3 if name != "fp32" else 1
+            steps = 3 if name == "fp16" else 1
             r.render_rays(rb[: n // 8], skts, cyl, want_alpha=False)
             torch.cuda.synchronize(dev)
             r.profile_enable(True); r.profile_read()

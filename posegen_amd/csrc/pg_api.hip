@@ -112,14 +112,14 @@ int fail(pg_handle* h, int code, const char* fmt, ...) {
 
 bool is_shape_a(int prec) { return prec == PG_PREC_BF16 || prec == PG_PREC_FP16; }
 
-// The split-operand modes are EXPERIMENTAL: on MI355X their kernels intermittently produce
-// wrong view-layer outputs for lanes 16..31 of some waves (DESIGN.md "Known issues").  They
-// stay compiled for investigation but must be enabled explicitly.
+// bf16x3 (every product as hi*hi + hi*lo + lo*hi of bf16 halves) is the 1e-4-grade mode at MFMA
+// speed.  fp16x3 stays EXPERIMENTAL: the low half of a small value underflows fp16's exponent
+// range, so it is no better than plain fp16 there (DESIGN.md "Known issues"); opt-in only.
 bool x3_allowed() {
     const char* e = std::getenv("POSEGEN_EXPERIMENTAL_X3");
     return e && e[0] == '1';
 }
-bool is_x3(int prec) { return prec == PG_PREC_BF16X3 || prec == PG_PREC_FP16X3; }
+bool is_x3(int prec) { return prec == PG_PREC_FP16X3; }
 
 pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     pgpack::NetTensors t;
