@@ -149,7 +149,11 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
         *reinterpret_cast<uint4*>(rtf + (i / 512) * SLOTF_BYTES + SLOTF_Y + (i % 512) * 16) = make_uint4(0, 0, 0, 0);
     st.start();
 
+#if defined(PG_STAMPS)
+    unsigned long long stamps[12];
+#endif
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        PG_STAMP(0);
         const long long p0 = (long long)it * PTS;
         const long long plast = min(p0 + PTS - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
         const float* cutd = opaque_ptr(cut + J + JH * h);
         const QFromAB q0{abp[0], zz[0]}, q1{abp[1], zz[1]};
 
+        PG_STAMP(1);
         V fa[HU][2], fb[HU][2];
         {   // ---- layer 0: K = 432 generated on the fly, all 8 out tiles of both column tiles live ----
             f32x16 acc[NT][2];
@@ -204,11 +209,13 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) relu_pack<V>(acc[o][c], fa[2 * o][c], fa[2 * o + 1][c], true);
         }
+        PG_STAMP(2);
         // ---- layers 1..4 ----
         hidden_layer_w<V>(fa, fb, st, bias, BT_LAYER0 + 1 * NT, h);
         hidden_layer_w<V>(fb, fa, st, bias, BT_LAYER0 + 2 * NT, h);
         hidden_layer_w<V>(fa, fb, st, bias, BT_LAYER0 + 3 * NT, h);
         hidden_layer_w<V>(fb, fa, st, bias, BT_LAYER0 + 4 * NT, h);
+        PG_STAMP(3);
         {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
             f32x16 acc[NT][2];
             APipeX<V> p5;
@@ -223,8 +230,10 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) relu_pack<V>(acc[o][c], fb[2 * o][c], fb[2 * o + 1][c], true);
         }
+        PG_STAMP(4);
         hidden_layer_w<V>(fb, fa, st, bias, BT_LAYER0 + 6 * NT, h);
         hidden_layer_w<V>(fa, fb, st, bias, BT_LAYER0 + 7 * NT, h);
+        PG_STAMP(5);
         // ---- sigma head + view layer (feature layer folded in, view directions factorised) ----
         float sigma[2];
         V fg[HU / 2][2];
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
                 row_tile_w<V, TAV>(s0, s1, pv, st, 0, fb);
                 sigma[0] = s0[0]; sigma[1] = s1[0];
             }
+            PG_STAMP(6);
 #pragma unroll
             for (int o = 0; o < NTV; ++o) {
                 vacc[o][0] = vacc[o][1] = load_bias(bias, BT_VIEWF + o, h);
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) relu_pack<V>(vacc[o][c], fg[2 * o][c], fg[2 * o + 1][c], true);
         }
+        PG_STAMP(7);
         // ---- rgb head ----
         f32x16 c0 = load_bias(bias, BT_RGB, h), c1 = c0;
         {
@@ -272,6 +283,15 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
             if (valid[0]) *reinterpret_cast<float4*>(a.raw + gp[0] * 4) = make_float4(c0[0], c0[1], c0[2], sigma[0]);
             if (valid[1]) *reinterpret_cast<float4*>(a.raw + gp[1] * 4) = make_float4(c1[0], c1[1], c1[2], sigma[1]);
         }
+        PG_STAMP(8);
+#if defined(PG_STAMPS)
+        if (a.dbg && a.dbg_stage == 99 && lane == 0 && it < 64) {
+            for (int k = 0; k < 9; ++k) reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + k] = stamps[k];
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 9] = st.t_vm;
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 10] = st.t_bar;
+            st.t_vm = 0; st.t_bar = 0;
+        }
+#endif
     }
     st.drain();
 }

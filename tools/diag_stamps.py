@@ -14,6 +14,8 @@ for rep in range(2):
     raw, dbg = r.stage_eval(0, rb, z, skts, want_dbg=True, dbg_stage=99)
 torch.cuda.synchronize()
 full = dbg.view(torch.int64).cpu().numpy().reshape(-1)[: 64 * 8 * 16].reshape(64, 8, 16)
+if os.environ.get("POSEGEN_WAVES") == "4":      # one-wave-per-SIMD kernel: rows 4..7 unused
+    full = full[:, :4]
 st = full[:, :, :9]
 print("per pass per wave: cycles waiting in vmcnt (weight DMA) %.0f, in s_barrier %.0f" % (full[1:, :, 9].mean(), full[1:, :, 10].mean()))
 print("   by wave: vmcnt", full[1:, :, 9].mean(0).astype(int).tolist(), " barrier", full[1:, :, 10].mean(0).astype(int).tolist())
