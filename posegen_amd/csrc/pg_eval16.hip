@@ -214,12 +214,14 @@ template <typename V, bool FC, bool FACT>
 static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval16_kernel<V, FC, FACT>;
     constexpr int LDS = FACT ? LDS_TOTAL_F : LDS_TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev != attr_dev) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_dev = dev;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS, stream, a);
     return hipGetLastError();

@@ -278,12 +278,14 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
 template <typename P, bool FC>
 static hipError_t launch_eval32(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval32_kernel<P, FC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    if (dev != attr_dev) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_dev = dev;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_B), LDS_TOTAL, stream, a);
     return hipGetLastError();
