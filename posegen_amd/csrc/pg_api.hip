@@ -509,12 +509,14 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     const bool sa = is_shape_a(precision);
     // 16-bit kernels: the factorised-view program (rays with >= 64 samples, the usual case)
     const bool fact = use_fact(precision, FACT_MIN_S);
-    if (stream_bytes) *stream_bytes = (int64_t)(sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK) : pgp::B::NCHUNK) * CHUNK_BYTES;
+    if (stream_bytes)
+        *stream_bytes = (int64_t)(sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK)
+                                     : (precision == PG_PREC_FP32 ? pgp::B::NCHUNK : pgp::B::NCHUNK_FOLD)) * CHUNK_BYTES;
     if (mfma_per_group) {
         // the fp32 / split kernels keep feature_linear and the direct view layer (13 + 4 out tiles)
         const int64_t direct = pgp::A::MFMA_PER_GROUP(fc) + (NT + 1 + NTV - (NTV + 1)) * pgp::A::HU;
         *mfma_per_group = sa ? (fact ? pgp::AF::MFMA_PER_GROUP(fc) : pgp::A::MFMA_PER_GROUP(fc))
-                             : (precision == PG_PREC_FP32 ? direct * 8 : direct * 3);
+                             : (precision == PG_PREC_FP32 ? direct * 8 : (direct - NT * pgp::A::HU) * 3);
     }
     return PG_OK;
 }

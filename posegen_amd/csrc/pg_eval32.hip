@@ -19,9 +19,10 @@ constexpr int NWAVE_B = 4;
 constexpr int NTHR_B = NWAVE_B * 64;
 constexpr int PTS_B = NWAVE_B * 32;
 
-using Stream32 = Stream<NWAVE_B, NCHUNK>;
+template <bool FOLD> using Stream32T = Stream<NWAVE_B, (FOLD ? NCHUNK_FOLD : NCHUNK)>;
 
 struct PolF32 {
+    static constexpr bool FOLD = false;         // the parity mode composes the network as the reference does
     static constexpr int UE = 4;                // values per lane per unit
     static constexpr int UBYTES = 1024;
     static constexpr int UPC = CHUNK_BYTES / UBYTES;
@@ -54,6 +55,7 @@ template <> struct Split<f16x8> {
 
 template <typename V>
 struct PolX3 {
+    static constexpr bool FOLD = true;          // feature_linear folded into the view layer (pg_pack.cpp)
     static constexpr int UE = 8;
     static constexpr int UBYTES = 2048;          // hi plane then lo plane
     static constexpr int UPC = CHUNK_BYTES / UBYTES;
@@ -83,8 +85,8 @@ struct PolX3 {
 };
 
 // one input unit (values x[0..UE)) against NO out tiles; unit index uu of a k-major segment
-template <typename P, int NO>
-__device__ __forceinline__ void mma_row(f32x16* acc, Stream32& st, int cbase, int uu, const float* x) {
+template <typename P, int NO, typename ST>
+__device__ __forceinline__ void mma_row(f32x16* acc, ST& st, int cbase, int uu, const float* x) {
     const typename P::B b = P::prep(x);
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
@@ -95,14 +97,14 @@ __device__ __forceinline__ void mma_row(f32x16* acc, Stream32& st, int cbase, in
 }
 
 // `nvals` consecutive lane values starting at sequence index i0 (multiples of UE)
-template <typename P, int NO>
-__device__ __forceinline__ void feed(f32x16* acc, Stream32& st, int cbase, int i0, const float* x, int nvals) {
+template <typename P, int NO, typename ST>
+__device__ __forceinline__ void feed(f32x16* acc, ST& st, int cbase, int i0, const float* x, int nvals) {
 #pragma unroll
     for (int t = 0; t < nvals / P::UE; ++t) mma_row<P, NO>(acc, st, cbase, i0 / P::UE + t, x + t * P::UE);
 }
 
-template <typename P>
-__device__ __forceinline__ void x_segment(f32x16* acc, Stream32& st, int cbase, const float* slot,
+template <typename P, typename ST>
+__device__ __forceinline__ void x_segment(f32x16* acc, ST& st, int cbase, const float* slot,
                                           const float* cut, float tau, float px, float py, float pz, int h) {
 #pragma unroll
     for (int sb = 0; sb < 3; ++sb) {
@@ -121,8 +123,8 @@ __device__ __forceinline__ void x_segment(f32x16* acc, Stream32& st, int cbase, 
 }
 
 // acc[o] (+)= W * act over the `nvals` hidden values of this lane (k-major)
-template <typename P, int NO>
-__device__ __forceinline__ void hidden_segment(f32x16* acc, Stream32& st, int cbase, const float* act, int nvals) {
+template <typename P, int NO, typename ST>
+__device__ __forceinline__ void hidden_segment(f32x16* acc, ST& st, int cbase, const float* act, int nvals) {
     feed<P, NO>(acc, st, cbase, 0, act, nvals);
 }
 
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, pt = lane & 31;
-    Stream32 st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+    Stream32T<P::FOLD> st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING)};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR_B) bias[i] = a.bias[i];
@@ -216,19 +218,24 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
             store_act<NT>(acc, act, true);
             dump_act<HSEQ>(a, l, gp, valid, act, h);
         }
-        // ---- feature (no activation) and sigma heads, both on h7 ----
+        // ---- feature (no activation) and sigma heads, both on h7; FOLD: no feature segment, the
+        // view layer's trunk part multiplies h7 by W_view[:, :256] W_feature ----
+        if (!P::FOLD) {
 #pragma unroll
-        for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_FEAT + o, h);
-        hidden_segment<P, NT>(acc, st, C_F, act, HSEQ);
+            for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_FEAT + o, h);
+            hidden_segment<P, NT>(acc, st, C_F, act, HSEQ);
+        }
         f32x16 acc1 = load_bias(bias, BT_ALPHA, h);
         hidden_segment<P, 1>(&acc1, st, C_ALPHA, act, HSEQ);
         const float sigma = acc1[0];
-        store_act<NT>(acc, act, false);
-        dump_act<HSEQ>(a, 8, gp, valid, act, h);
+        if (!P::FOLD) {
+            store_act<NT>(acc, act, false);
+            dump_act<HSEQ>(a, 8, gp, valid, act, h);
+        }
         // ---- view layer ----
         f32x16 accv[NTV];
 #pragma unroll
-        for (int o = 0; o < NTV; ++o) accv[o] = load_bias(bias, BT_VIEW + o, h);
+        for (int o = 0; o < NTV; ++o) accv[o] = load_bias(bias, (P::FOLD ? BT_VIEWF : BT_VIEW) + o, h);
         hidden_segment<P, NTV>(accv, st, C_VF, act, HSEQ);
         {
             float wd[JH];

@@ -64,6 +64,7 @@ float NetTensors::w(int mat, int row, int col) const {
     else if (mat == MAT_ALPHA) { p = alpha_w; rows = 1; cols = W; }
     else if (mat == MAT_VIEW) { p = view_w; rows = VW; cols = view_cols; }
     else if (mat == MAT_RGB) { p = rgb_w; rows = 3; cols = VW; }
+    else if (mat == MAT_VIEWF) { p = viewf_w.data(); rows = VW; cols = W; }
     else if (mat == MAT_ALPHA_VIEWF) {
         if (row < 32) { p = alpha_w; rows = 1; cols = W; }
         else { p = viewf_w.data(); rows = VW; cols = W; row -= 32; }
@@ -94,7 +95,7 @@ void NetTensors::fold() {
     }
 }
 
-static std::vector<Segment> program(int shape, bool fc, bool fact) {
+static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false) {
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
     const bool km = (shape == SHAPE_B);
@@ -106,9 +107,9 @@ static std::vector<Segment> program(int shape, bool fc, bool fact) {
     if (shape == SHAPE_A) {
         s.push_back({MAT_ALPHA_VIEWF, NTV + 1, false, {hid(0)}});
     } else {
-        s.push_back({MAT_FEAT, NT, true, {hid(0)}});
+        if (!fold_b) s.push_back({MAT_FEAT, NT, true, {hid(0)}});
         s.push_back({MAT_ALPHA, 1, true, {hid(0)}});
-        s.push_back({MAT_VIEW, NTV, km, {hid(0)}});
+        s.push_back({fold_b ? MAT_VIEWF : MAT_VIEW, NTV, km, {hid(0)}});
     }
     if (!fact) {
         Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
@@ -127,12 +128,12 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3;
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
     if (fact && shape != SHAPE_A) return -3;
-    if (shape == SHAPE_A && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
+    if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
     if (seg_chunk_base) seg_chunk_base->clear();
-    for (const Segment& sg : program(shape, fc, fact)) {
+    for (const Segment& sg : program(shape, fc, fact, split)) {
         if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
         // flatten the input units of this segment
         struct U { int seq, u, colbase; };
@@ -167,7 +168,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         }
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK) : B::NCHUNK;
+    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK) : (split ? B::NCHUNK_FOLD : B::NCHUNK);
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
 }

@@ -16,7 +16,8 @@ using namespace pgl;
 enum Seq { SEQ_X = 0, SEQ_H = 1, SEQ_D = 2, SEQ_CODE = 3 };
 enum Mat { MAT_L0 = 0, /* .. MAT_L7 = 7 */ MAT_FEAT = 8, MAT_ALPHA = 9, MAT_VIEW = 10, MAT_RGB = 11,
            MAT_FEAT_ALPHA = 12 /* tiles 0..7 feature_linear, tile 8 row 0 alpha_linear */,
-           MAT_ALPHA_VIEWF = 13 /* tile 0 row 0 alpha_linear, tiles 1..4 W_view[:, :256] W_feature */ };
+           MAT_ALPHA_VIEWF = 13 /* tile 0 row 0 alpha_linear, tiles 1..4 W_view[:, :256] W_feature */,
+           MAT_VIEWF = 14 /* W_view[:, :256] W_feature alone (split-operand kernels) */ };
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -94,6 +95,9 @@ constexpr int C_VD = C_VF + CH_VF;
 constexpr int CH_VD = cdiv((DSEQ + 8) * NTV, VPC);
 constexpr int C_RGB = C_VD + CH_VD;
 constexpr int NCHUNK = C_RGB + 1;
+// split-operand precisions fold feature_linear into the view layer (as the 16-bit kernels do):
+// the feature segment disappears, the view layer's trunk part reads the last trunk activation
+constexpr int NCHUNK_FOLD = NCHUNK - CH_HID;
 static_assert(cdiv(DSEQ * NTV, VPC) == CH_VD, "view segment must take the same chunks with and without frame code");
 }  // namespace B
 
