@@ -193,6 +193,15 @@ int pg_stage_eval(pg_handle* h, void* stream, int which_net, int64_t n, int n_sa
                   const float* ray_batch, const float* z, const float* skts,
                   int64_t pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage);
 
+/* Density query on explicit points: replaces RayCaster.render_pts_density
+ * / the forward function of _get_density_fwd_fn (core/raycasters.py:598-646) for one pose:
+ * bone-relative embedding of pts [n_points,3] (device) + the trunk of net `which_net`.
+ * raw [n_points,4] device: raw[:,3] = alpha_linear output (the reference's raw density, no
+ * activation); raw[:,0:3] = rgb_raw for a zero view direction (ignore).  The frame code, if the
+ * model has one, is the mean code. */
+int pg_query_density(pg_handle* h, void* stream, int which_net, int64_t n_points, const float* pts,
+                     const float* skts, float* raw);
+
 /* raw2outputs (nerf.py:150-205) and, if n_importance > 0, isample_from_lineseg
  * (ray_utils.py:157-201, 255-289): wave-per-ray prefix-product compositing. */
 int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,

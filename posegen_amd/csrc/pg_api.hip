@@ -217,9 +217,10 @@ int check_ready(pg_handle* h, bool need_fine) {
 }
 
 int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
-                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0) {
+                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
+                const float* points = nullptr) {
     const int prec = h->cfg.precision;
-    const bool fact = use_fact(prec, S);
+    const bool fact = !points && use_fact(prec, S);      // explicit points: the direct kernel (q = R p + t)
     int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const bool small = fact && use_small_tiles();
@@ -228,7 +229,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
-    a.rays = rays; a.z = z; a.skts = skts; a.cams = cams;
+    a.rays = rays; a.z = z; a.pts = points; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
     a.wstream = small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
     a.wy = fact ? ns.d_vy[prec] : nullptr;
@@ -545,6 +546,24 @@ int pg_stage_eval(pg_handle* h, void* stream, int which, int64_t n, int n_sample
     if (n == 0) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
     return launch_eval(h, stream, which, n, n_samples, ray_batch, z, skts, pose_stride, cams, raw, dbg, dbg_stage);
+}
+
+int pg_query_density(pg_handle* h, void* stream, int which, int64_t n_points, const float* pts, const float* skts,
+                     float* raw) {
+    int rc = check_ready(h, which == 1);
+    if (rc) return rc;
+    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_query_density: which_net must be 0 or 1");
+    if (n_points < 0 || !pts || !skts || !raw) return fail(h, PG_EINVAL, "pg_query_density: null/negative argument");
+    if (n_points > 0x7fffffffLL) return fail(h, PG_EINVAL, "pg_query_density: at most 2^31-1 points per call");
+    if (n_points == 0) return PG_OK;
+    PG_HIP(h, hipSetDevice(h->device));
+    // one pseudo ray (o = d = 0) that owns all points: the kernels take the pose and the view table
+    // from the ray slot, the position from `pts`
+    rc = ensure_ws(h, 256);
+    if (rc) return rc;
+    PG_HIP(h, hipMemsetAsync(h->ws, 0, 64, static_cast<hipStream_t>(stream)));
+    return launch_eval(h, stream, which, 1, (int)n_points, reinterpret_cast<const float*>(h->ws), nullptr, skts, 0,
+                       nullptr, raw, nullptr, 0, pts);
 }
 
 int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, const float* ray_batch, const float* z,

@@ -78,13 +78,17 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
         const float* tab = FACT ? nullptr : opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
-        const float zz = a.z[gpc];
+        const float zz = (!FACT && a.pts) ? 0.0f : a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
         float px = 0.0f, py = 0.0f, pz = 0.0f;
         if (!FACT) {
-            px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
-            py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
-            pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
+            if (a.pts) {        // density query on explicit points (pg_query_density)
+                px = a.pts[gpc * 3]; py = a.pts[gpc * 3 + 1]; pz = a.pts[gpc * 3 + 2];
+            } else {
+                px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
+                py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
+                pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
+            }
         }
         const QFromRows q_rows{skb, px, py, pz};
         const QFromAB q_ab{skb, zz};

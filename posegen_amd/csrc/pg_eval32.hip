@@ -175,10 +175,11 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
         const float* slot = rtab + ((int)(gpc / a.S) - r0) * SLOT_FLOATS;
-        const float zz = a.z[gpc];
-        const float px = __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
-        const float py = __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
-        const float pz = __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
+        const float zz = a.pts ? 0.0f : a.z[gpc];
+        // explicit points (pg_query_density) or p = o + d z as the reference forms it (mul, then add)
+        const float px = a.pts ? a.pts[gpc * 3 + 0] : __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
+        const float py = a.pts ? a.pts[gpc * 3 + 1] : __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
+        const float pz = a.pts ? a.pts[gpc * 3 + 2] : __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
 
         float act[HSEQ];
         f32x16 acc[NT];

@@ -236,6 +236,31 @@ class HipRenderer:
             _ptr(rgb8)))
         return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
 
+    def query_density(self, pts: torch.Tensor, skts: torch.Tensor, which: Optional[int] = None) -> torch.Tensor:
+        """Raw density (alpha_linear output, no activation) of net `which` (default: the fine net if
+        loaded, like the reference) at explicit points [...,3] for one pose: render_pts_density
+        (core/raycasters.py:598-646).  Returns a device tensor [..., 1]."""
+        if which is None:
+            which = 1 if "network_fine_state_dict" in self._state else 0
+        p = _dev_f32(torch.as_tensor(pts).reshape(-1, 3), self.device)
+        n = p.shape[0]
+        sk, _ = self._pose_args(skts, 1)
+        raw = torch.empty(n, 4, device=self.device)
+        if n > 0:
+            self._check(self.lib.pg_query_density(self.handle, self._stream(), int(which), n, _ptr(p), _ptr(sk), _ptr(raw)))
+        return raw[:, 3:4].reshape(*torch.as_tensor(pts).shape[:-1], 1)
+
+    def mesh_density(self, kps: torch.Tensor, skts: torch.Tensor, radius: float = 1.0, res: int = 64,
+                     which: Optional[int] = None) -> torch.Tensor:
+        """Raw density on the (res+1)^3 grid of half-width `radius` around the root joint, laid out
+        like RayCaster.render_mesh_density (core/raycasters.py:579-596)."""
+        t = np.linspace(-radius, radius, res + 1)
+        grid = np.stack(np.meshgrid(t, t, t), axis=-1).astype(np.float32)
+        sh = grid.shape
+        pts = torch.tensor(grid.reshape(-1, 3)) + torch.as_tensor(kps, dtype=torch.float32).reshape(-1, 24, 3)[0, 0]
+        d = self.query_density(pts, skts, which)
+        return d.reshape(*sh[:-1]).transpose(1, 0)
+
     def pose_kinematics(self, bones: torch.Tensor, rest_pose, parents=None, want_l2ws: bool = False):
         """bones [F,24,3] axis-angle (any device/dtype) -> device kps [F,24,3] f32, skts [F,24,4,4] f32
         (+ l2ws f64), computed on the device in float64 (pg_pose_kinematics; the host equivalent is

@@ -312,3 +312,28 @@ def test_errors_are_loud(casters):
     r.close()
     with pytest.raises(_ffi.PgError):
         HipRenderer(surreal_config(multires=10), DEV)
+
+
+@pytest.mark.parametrize("prec,tol", [(PREC_FP32, 2e-4), (PREC_BF16X3, 3e-3), (PREC_FP16, 8e-3), (PREC_BF16, 5e-2)])
+def test_query_density_on_explicit_points(casters, prec, tol):
+    """pg_query_density (render_pts_density of the reference: raw alpha_linear output at arbitrary
+    points, fine net) against the oracle's embedding + trunk on the same points."""
+    g = load_golden("rays_surreal")
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), prec)
+    rb, skts, cyl, cams = _inputs(g)
+    z = torch.tensor(g["z_coarse"])
+    n = 77                                        # 77 * 64 points: not a multiple of a pass
+    pts = (rb[:n, None, 0:3] + rb[:n, None, 3:6] * z[:n, :, None]).reshape(-1, 3)
+    pts = pts + 0.01 * torch.randn(pts.shape, generator=torch.Generator().manual_seed(1))   # off the rays
+    dens = c.renderer.query_density(pts, skts).cpu()
+    ocfg, wc, wf = _oracle_stage(g, cfg, None)
+    x = orc.embed_points(pts[:, None, :], torch.zeros(pts.shape[0], 3) + torch.tensor([0., 0., 1.]), skts, ocfg)
+    ref = orc.mlp_forward(x.reshape(pts.shape[0], -1), wf, ocfg)[:, 3:4]
+    scale = float(ref.abs().max())
+    d = _maxdiff(dens.numpy(), ref.numpy())
+    print(f"[{PREC_NAMES[prec]}] raw density at {pts.shape[0]} points: maxdiff {d:.3e} (|sigma_raw| max {scale:.1f})")
+    assert dens.shape == (pts.shape[0], 1)
+    assert d <= tol * max(1.0, scale / 10)
+    grid = c.renderer.mesh_density(torch.tensor(g["kps"]) if "kps" in g else pts[:24][None], skts, radius=0.6, res=8)
+    assert grid.shape == (9, 9, 9) and torch.isfinite(grid).all()
