@@ -346,6 +346,23 @@ class HipRayCaster:
         rc.renderer.set_embedder(1, tau_d)
         return rc
 
+    # ---- density queries (core/raycasters.py:579-646) ----------------------------------------
+    def render_pts_density(self, pts, kps, skts, bones=None, render_kwargs=None, subject_idxs=None,
+                           netchunk=1024 * 64, network=None, color=False, v=None):
+        """Raw density [..., 1] at points `pts` [n,1,3] (or [n,3]) for one pose; fine net unless
+        `network` is 0/1.  `kps`, `bones`, `netchunk` are accepted for call compatibility."""
+        if color or v is not None or subject_idxs is not None:
+            raise NotImplementedError("render_pts_density: color / precomputed v / subject_idxs are not supported")
+        which = network if network in (0, 1) else None
+        return self.renderer.query_density(torch.as_tensor(pts), skts, which)
+
+    def render_mesh_density(self, kps, skts, bones=None, subject_idxs=None, radius=1.0, res=64,
+                            render_kwargs=None, netchunk=1024 * 64, v=None):
+        """Raw density on the (res+1)^3 grid around the root joint, as the reference lays it out."""
+        if v is not None or subject_idxs is not None:
+            raise NotImplementedError("render_mesh_density: precomputed v / subject_idxs are not supported")
+        return self.renderer.mesh_density(kps, skts, radius=radius, res=res)
+
     # ---- nn.Module-like surface the reference touches -------------------------------
     @property
     def module(self):            # trainer.py:267,272,506 reach through DataParallel
