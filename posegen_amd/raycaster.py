@@ -405,13 +405,21 @@ class HipRayCaster:
                 raise KeyError(key)
 
     # ---- the call -------------------------------------------------------------------
+    def __call__(self, *args, fwd_type="", **kwargs):
+        # the reference dispatches on fwd_type before anything else (core/raycasters.py:349-359)
+        if fwd_type == "density":
+            return self.render_pts_density(*args, **kwargs)
+        if fwd_type == "mesh":
+            return self.render_mesh_density(*args, **kwargs)
+        return self.forward(*args, fwd_type=fwd_type, **kwargs)
+
     def forward(self, ray_batch, N_samples=None, kp_batch=None, skts=None, cyls=None, bones=None,
                 cams=None, subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0,
                 network_fine=None, raw_noise_std=0., ray_noise_std=0., verbose=False, ext_scale=0.001,
                 pytest=False, preproc_kwargs=None, nerf_type="nerf", fwd_type="", use_viewdirs=True,
                 want_alpha=True, extras=False, **unused):
         if fwd_type:
-            raise NotImplementedError(f"fwd_type={fwd_type!r} (density / mesh queries) is not on the HIP path")
+            raise NotImplementedError(f"fwd_type={fwd_type!r} is not on the HIP path ('density' and 'mesh' are)")
         if self.training or perturb or raw_noise_std or ray_noise_std:
             raise NotImplementedError("HipRayCaster renders in eval mode only (perturb = noise = 0)")
         if subject_idxs is not None:
@@ -422,7 +430,6 @@ class HipRayCaster:
                                          n_importance=N_importance, lindisp=bool(lindisp),
                                          want_alpha=want_alpha, extras=extras)
 
-    __call__ = forward
 
 
 def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PREC_BF16):

@@ -337,3 +337,6 @@ def test_query_density_on_explicit_points(casters, prec, tol):
     assert d <= tol * max(1.0, scale / 10)
     grid = c.renderer.mesh_density(torch.tensor(g["kps"]) if "kps" in g else pts[:24][None], skts, radius=0.6, res=8)
     assert grid.shape == (9, 9, 9) and torch.isfinite(grid).all()
+    # the reference's dispatch: caster(pts, kps, skts, bones, fwd_type='density')
+    via_call = c(pts[:, None, :], None, skts, None, fwd_type="density").cpu()
+    assert torch.equal(via_call.reshape(-1, 1), dens)
