@@ -168,6 +168,11 @@ def main():
                      "points_per_launch": k_pts / max(launches, 1), "flop_per_point": flops_pt,
                      "end_to_end_frac": rays_s / world * flops_pt * cfg.evals_per_ray() / 1e12 / peak},
     }
+    # the peak re-derived on this box: CUs x 4 SIMDs x 1024 bf16 MFMA FLOP/clk x max clock
+    di = r.device_info()
+    if di["clock_khz"] > 0 and a.prec in ("bf16", "fp16", "bf16x3"):
+        result["roofline"]["peak_derived"] = di["n_cu"] * 4 * 1024 * di["clock_khz"] * 1e3 / 1e12
+        result["roofline"]["peak_derived_from"] = f"{di['n_cu']} CUs x 4096 FLOP/clk x {di['clock_khz'] / 1e6:.2f} GHz (hipDeviceProp)"
     # `achieved` counts the ALGORITHMIC flops of the reference network.  The 16-bit
     # kernels execute fewer: feature_linear is folded into the view layer and the view-direction
     # input is factorised over rays, both exact in real arithmetic.  The MFMA

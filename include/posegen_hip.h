@@ -231,6 +231,10 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
 int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
                      int precision, uint8_t* out, int64_t cap, int64_t* out_bytes);
 
+/* Compute units and maximum engine clock [kHz] of the handle's device (hipDeviceProp), for
+ * re-deriving the MFMA peak on the box: n_cu x 4 SIMDs x 1024 bf16 FLOP/clk x clock. */
+int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz);
+
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision (16-bit precisions:
  * of the factorised-view program used when a ray has >= 64 samples). */

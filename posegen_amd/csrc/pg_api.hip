@@ -74,6 +74,7 @@ struct pg_handle {
     pg_config cfg;
     int device = 0;
     int n_cu = 256;
+    int clock_khz = 0;
     char err[512] = "";
     NetState net[2];
     float cut[48];
@@ -313,6 +314,7 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
         return fail(nullptr, PG_EHIP, "pg_create: cannot query device");
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->clock_khz = prop.clockRate;
     if (hipMalloc(reinterpret_cast<void**>(&h->d_cut), 48 * sizeof(float)) != hipSuccess) {
         delete h;
         return fail(nullptr, PG_ENOMEM, "pg_create: device allocation failed");
@@ -500,6 +502,13 @@ int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_t
         if ((int64_t)vy.size() > cap) return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: buffer too small");
         std::memcpy(out, vy.data(), vy.size());
     }
+    return PG_OK;
+}
+
+int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_device_info: null handle");
+    if (n_cu) *n_cu = h->n_cu;
+    if (clock_khz) *clock_khz = h->clock_khz;
     return PG_OK;
 }
 

@@ -128,6 +128,11 @@ class HipRenderer:
         self._check(self.lib.pg_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(pts)))
         return n.value, ms.value, pts.value
 
+    def device_info(self):
+        n, k = C.c_int32(), C.c_int32()
+        self._check(self.lib.pg_device_info(self.handle, C.byref(n), C.byref(k)))
+        return {"n_cu": n.value, "clock_khz": k.value}
+
     def query(self, precision=None):
         sb, mf = C.c_int64(), C.c_int64()
         self._check(self.lib.pg_query(self.handle, self.precision if precision is None else int(precision),
