@@ -2,7 +2,9 @@
 """Audit of the hand-issued ring reads in the compiled eval16 kernels (guide 5.7): between
 an inline-asm `ds_read_b128 vDST, vA offset:N*1024` and the MFMA that consumes vDST there must
 be (a) an inline-asm s_waitcnt and (b) no other instruction touching vDST (a compiler copy or
-spill of a register whose load has not landed would read garbage).
+spill of a register whose load has not landed would read garbage); and (c) no scalar memory load
+may be issued while a hand-issued read is in flight: SMEM shares lgkmcnt with LDS and returns out
+of order, so a counted lgkmcnt wait would no longer prove that the LDS read has landed.
 usage: audit_asm_loads.py kernel.s"""
 import re, sys
 txt = open(sys.argv[1]).read()
@@ -28,6 +30,8 @@ for k in kernels:
             pending[int(m.group(1))] = (i, regs, False)
             n_loads += 1
             continue
+        if re.match(r's_(buffer_)?load_', t) and pending:
+            print(f"{name}: line {i}: [{t}] scalar load while {len(pending)} hand-issued LDS reads are in flight"); bad += 1
         if t.startswith('s_waitcnt lgkmcnt'):
             for key in pending:
                 l0, r0, _ = pending[key]
