@@ -1,37 +1,89 @@
 #!/usr/bin/env python3
 """Headline benchmark: rendered rays/s of the A-NeRF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 One step = one 512x512 frame per GPU (262 144 rays, 64 coarse + 16 importance samples per
 ray -> 144 MLP point evaluations per ray, both nets, synthetic surreal-config weights),
-rendered by `pg_render_rays` with the ray batch already resident in HBM.  With N > 1 every
-rank renders its own frame (image-parallel, weak scaling) and the frames are reassembled on
-every rank by one RCCL all-gather of the packed (rgb, disp, acc) maps inside the timed region.
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+rendered by `pg_render_rays` with the ray batch already resident in HBM.  With N > 1 there is
+one process per GPU (`torch.distributed`, backend nccl = RCCL): started by the driver through
+`python -m torch.distributed.run`, or -- when `--gpus N` is given without a rendezvous in the
+environment -- by this script itself, as a child process launched before anything touches the
+GPU.  Every rank renders its own frame (image-parallel, weak scaling) and the frames are
+reassembled on every rank by one all-gather of the packed (rgb, disp, acc) maps, fed from
+device memory, inside the timed region.  Rank 0 prints ONE JSON line (README / DESIGN.md).
+
+Besides the headline the line carries (N = 1 only, each after the timed region):
+  roofline       hipEvent time of the fused embed+MLP kernel vs the MFMA peak
+  cpu_baseline   the oracle (CPU port of the reference path) on a bounded sample, config 2
+  cpu_baselines  the same for config 1 (128x128, 32 samples per ray)
+  host_to_host   SURVEY 8(d)'s frame metric: poses on host -> frames on host through render_path
+  workloads      BASELINE config 4 (h36m: 128+16 samples, frame codes) on one 512x512 frame
+  modes          the other precision modes on the headline workload
+`--dry-run` replaces the renderer by a stub and the backend by gloo: the launch / barrier /
+max-over-ranks / gather / JSON plumbing on CPU (tests/test_host_logic.py).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from posegen_amd import PREC_BY_NAME, PREC_NAMES, surreal_config, synthetic as syn  # noqa: E402
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0, "fp16c": 2500.0}
+METRIC = "rendered rays/sec (512x512, 64 samples/ray)"
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0}
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prec", default="bf16")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--cpu-rays", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-precision side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / workloads / cpu_baselines")
+    ap.add_argument("--dry-run", action="store_true", help="stub renderer on CPU, gloo backend (plumbing test)")
+    return ap.parse_args(argv)
 
 
-def full_frame_rays(H, W, device):
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` outside a rendezvous: start one process per GPU as a CHILD
+    (nothing in this process has touched the GPU) and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if out.returncode != 0 or line is None:
+        print(f"bench.py: the {a.gpus}-process run failed (exit code {out.returncode})", file=sys.stderr)
+        return out.returncode or 1
+    print(line)
+    return 0
+
+
+def full_frame_rays(H, W, device, cfg=None):
     """All H*W rays of the synthetic camera, cylinder radius 2.5 so that every ray hits
     (SURVEY.md 8(d) 'full' variant).  Ray formula of the reference's get_rays."""
+    import torch
+    from posegen_amd import synthetic as syn
+    from posegen_amd.skeleton import get_kp_bounding_cylinder
     _, kps, skts = syn.make_pose(1, 1)
     c2ws, focals = syn.make_camera(1, H, W)
     c2w = torch.tensor(c2ws[0])
@@ -44,15 +96,15 @@ def full_frame_rays(H, W, device):
     vd = rd / torch.norm(rd, dim=-1, keepdim=True)
     n = rd.shape[0]
     rb = torch.cat([ro, rd, torch.zeros(n, 1), torch.ones(n, 1), vd], -1).contiguous()
-    from posegen_amd.skeleton import get_kp_bounding_cylinder
     cyl = torch.tensor(get_kp_bounding_cylinder(kps, ext_scale=0.001), dtype=torch.float32)
     cyl[:, 2] = 2.5
     return rb.to(device), torch.tensor(skts).to(device), cyl.to(device), rb, torch.tensor(skts), cyl
 
 
-def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays):
+def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays, what):
     """The oracle (CPU port of the reference path) timed on the host cores, on a bounded
-    sample of the same workload."""
+    sample of the workload `what`."""
+    import torch
     from oracle import anerf_oracle as orc
     wc, wf, tv, td = model
     ocfg = orc.OracleConfig(tau_v=tv, tau_d=td)
@@ -61,7 +113,8 @@ def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays):
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     n = rb_cpu.shape[0]
-    start = (n // 2 // 512) * 512 + 128            # rows through the body
+    n_rays = min(n_rays, n)
+    start = min((n // 2 // 512) * 512 + 128, n - n_rays)     # rows through the body
     sel = torch.arange(start, start + n_rays)
     sample = rb_cpu[sel]
     with torch.no_grad():
@@ -70,50 +123,110 @@ def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays):
         ref = orc.render_rays(sample, skts_cpu, cyl_cpu, ocfg, tw(wc), tw(wf), cfg.n_samples, cfg.n_importance)
         dt = time.time() - t0
     return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays} consecutive rays of the same 512x512 frame, one oracle call, "
+            "sample": f"{n_rays} consecutive rays of {what}, one oracle call, "
                       f"torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}, sel, ref
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--prec", default="bf16", choices=list(PREC_BY_NAME))
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--cpu-rays", type=int, default=8192)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-modes", action="store_true", help="skip the per-precision side measurements")
-    a = ap.parse_args()
+def timed_rays(r, dev, rb, skts, cyl, cfg, steps, cams=None):
+    """(rays/s, ms/frame, kernel TFLOP/s on algorithmic flops) of `steps` render_rays calls."""
+    import torch
+    r.render_rays(rb[: max(rb.shape[0] // 8, 4096)], skts, cyl, cams=None if cams is None else cams[: max(rb.shape[0] // 8, 4096)],
+                  n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
+    torch.cuda.synchronize(dev)
+    r.profile_enable(True)
+    r.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render_rays(rb, skts, cyl, cams=cams, n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    launches, ms, pts = r.profile_read()
+    r.profile_enable(False)
+    tf = pts * cfg.flops_per_point() / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return rb.shape[0] * steps / dt, dt / steps * 1e3, tf, ms / max(launches, 1)
 
+
+def host_to_host(caster, cfg, dev, H, W, frames=4):
+    """pose tensors on host -> rgb/disp/acc frames on host, reference bbox cull."""
+    import torch
+    from posegen_amd import synthetic as syn
+    from posegen_amd.render import render_path
+    _, kps, skts = syn.make_pose(frames, 1)
+    c2ws, focals = syn.make_camera(frames, H, W)
+    kps, skts, c2ws = torch.tensor(kps), torch.tensor(skts), torch.tensor(c2ws)
+    kw = {"ray_caster": caster, "N_importance": cfg.n_importance, "N_samples": cfg.n_samples, "lindisp": False}
+    run = lambda: render_path(c2ws, (H, W, focals), 4096, kw, kp=kps, skts=skts, white_bkgd=True, ret_acc=True,
+                              ext_scale=cfg.ext_scale)
+    out = run()
+    n_valid = sum(len(v) for v in out[3])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    return {"valid_rays_per_s": n_valid / dt, "pixels_per_s": frames * H * W / dt, "ms_per_frame": dt / frames * 1e3,
+            "frames": frames, "valid_rays": n_valid,
+            "what": f"render_path: {frames} poses + cameras on host -> float32 rgb/disp/acc frames {H}x{W} on host, "
+                    "reference bounding-cylinder cull (rays counted = rays inside the box), chunk 4096, "
+                    "includes box projection on the host, per-frame launches and the device->host copies"}
+
+
+def dry_run_step(n, rank):
+    """Stub of one step for --dry-run: a deterministic [n,5] 'frame' without a renderer."""
+    import torch
+    v = torch.arange(n, dtype=torch.float32)[:, None] * 1e-3 + rank
+    return {"rgb_map": v.expand(n, 3), "disp_map": v[:, 0], "acc_map": v[:, 0]}
+
+
+def main():
+    a = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the rendezvous has WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    from posegen_amd import PREC_BY_NAME, h36m_config, surreal_config, synthetic as syn
+    if a.prec not in PREC_BY_NAME:
+        sys.exit(f"bench.py: unknown precision {a.prec!r} (one of {sorted(PREC_BY_NAME)})")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N>1 must run under torch.distributed.run (one process per GPU)")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    if a.dry_run:
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=dev)
 
-    from posegen_amd.raycaster import HipRayCaster
     cfg = surreal_config()
-    model = syn.make_model(cfg, 0)
-    caster = HipRayCaster.from_weights(cfg, *model, device=dev, precision=a.prec)
     H = W = a.res
-    rb, skts, cyl, rb_cpu, skts_cpu, cyl_cpu = full_frame_rays(H, W, dev)
-    n = rb.shape[0]
-    r = caster.renderer
+    if a.dry_run:
+        n, r, caster = H * W, None, None
+    else:
+        from posegen_amd.raycaster import HipRayCaster
+        model = syn.make_model(cfg, 0)
+        caster = HipRayCaster.from_weights(cfg, *model, device=dev, precision=a.prec)
+        rb, skts, cyl, rb_cpu, skts_cpu, cyl_cpu = full_frame_rays(H, W, dev)
+        n = rb.shape[0]
+        r = caster.renderer
+        r.set_chunk(cfg.chunk)
     packed = torch.empty(n, 5, device=dev)
-    gathered = torch.empty(world, n, 5, device=dev) if world > 1 else None
+    gathered = torch.empty(world * n, 5, device=dev) if world > 1 else None
 
     def step():
-        out = r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance,
-                            want_alpha=False)
-        if world > 1:           # reassemble the frames of all ranks: one RCCL all-gather
+        out = dry_run_step(n, rank) if a.dry_run else r.render_rays(
+            rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
+        if world > 1:           # reassemble the frames of all ranks: one all-gather, device to device
             packed[:, 0:3] = out["rgb_map"]
             packed[:, 3] = out["disp_map"]
             packed[:, 4] = out["acc_map"]
@@ -123,24 +236,30 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not a.dry_run:
+            torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
         step()
     sync()
-    r.profile_enable(True)
-    r.profile_read()
+    if r is not None:
+        r.profile_enable(True)
+        r.profile_read()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     sync()
     dt = time.perf_counter() - t0
-    launches, k_ms, k_pts = r.profile_read()
-    r.profile_enable(False)
+    launches, k_ms, k_pts = r.profile_read() if r is not None else (0, 0.0, 0)
+    if r is not None:
+        r.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if a.dry_run:           # the gathered frames are every rank's frame, in rank order
+            for k in range(world):
+                assert float(gathered[k * n, 0]) == float(k), "all-gather order"
 
     if rank != 0:
         if world > 1:
@@ -152,25 +271,33 @@ def main():
     rays_s = world * n * a.steps / dt
     peak = PEAK_TFLOPS[a.prec]
     k_tflops = k_pts * flops_pt / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    kernel = {"bf16": "eval16_kernel", "fp16": "eval16_kernel", "fp16c": "evalc_kernel"}.get(a.prec, "eval32_kernel")
     result = {
-        "metric": "rendered rays/sec (512x512, 64 samples/ray)",
+        "metric": METRIC,
         "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
+        "vs_baseline": None, "dtype": a.prec, "data": "synthetic (dry run: stub renderer, no GPU)" if a.dry_run else "synthetic",
         "config": {"workload": f"surreal {H}x{W} full frame per GPU ({n} rays, all rays hit: cylinder radius 2.5), "
                                f"{cfg.n_samples} coarse + {cfg.n_importance} importance samples/ray = "
                                f"{cfg.evals_per_ray()} MLP evals/ray (coarse + fine net), seeded synthetic weights/pose",
                    "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}" if world > 1 else "single GPU",
                    "flop_per_ray": flops_pt * cfg.evals_per_ray()},
-        "roofline": {"bound": "mfma", "kernel": "eval16_kernel (fused embed+MLP)" if a.prec in ("bf16", "fp16") else "eval32_kernel",
+        "roofline": {"bound": "mfma", "kernel": f"{kernel} (fused embed+MLP)",
                      "achieved": k_tflops, "peak": peak, "unit": "TFLOP/s", "frac": k_tflops / peak,
                      "traffic": None, "launches": launches, "avg_launch_ms": k_ms / max(launches, 1),
                      "points_per_launch": k_pts / max(launches, 1), "flop_per_point": flops_pt,
                      "end_to_end_frac": rays_s / world * flops_pt * cfg.evals_per_ray() / 1e12 / peak},
     }
+    if a.dry_run:
+        print(json.dumps(result))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # the peak re-derived on this box: CUs x 4 SIMDs x 1024 bf16 MFMA FLOP/clk x max clock
     di = r.device_info()
-    if di["clock_khz"] > 0 and a.prec in ("bf16", "fp16", "bf16x3"):
+    if di["clock_khz"] > 0 and a.prec != "fp32":
         result["roofline"]["peak_derived"] = di["n_cu"] * 4 * 1024 * di["clock_khz"] * 1e3 / 1e12
         result["roofline"]["peak_derived_from"] = f"{di['n_cu']} CUs x 4096 FLOP/clk x {di['clock_khz'] / 1e6:.2f} GHz (hipDeviceProp)"
     # `achieved` counts the ALGORITHMIC flops of the reference network.  The 16-bit
@@ -178,26 +305,27 @@ def main():
     # input is factorised over rays, both exact in real arithmetic.  The MFMA
     # flops actually issued are reported beside it.
     q = r.query()
-    mfma_flop = {"bf16": 32768, "fp16": 32768, "bf16x3": 32768, "fp32": 4096}.get(a.prec)
-    if mfma_flop:
-        ex = q["mfma_per_group"] * mfma_flop / 32.0
-        result["roofline"]["executed_flop_per_point"] = ex
-        result["roofline"]["executed_tflops"] = k_tflops * ex / flops_pt
-        result["roofline"]["executed_frac"] = k_tflops * ex / flops_pt / peak
+    mfma_flop = 4096 if a.prec == "fp32" else 32768
+    ex = q["mfma_per_group"] * mfma_flop / 32.0
+    result["roofline"]["executed_flop_per_point"] = ex
+    result["roofline"]["executed_tflops"] = k_tflops * ex / flops_pt
+    result["roofline"]["executed_frac"] = k_tflops * ex / flops_pt / peak
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
-    # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r1_traffic.json);
-    # bench.py cannot run the profiler on itself, so the committed measurement is attached.
-    tpath = os.path.join(REPO, "profiles", "r1_traffic.json")
-    if a.prec == "bf16" and H == 512 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        result["roofline"]["traffic"] = tj["hbm_bytes"]
-        result["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/r1_traffic.json)"
-        result["roofline"]["algorithmic_bytes_per_launch"] = tj["algorithmic_bytes"]
+    # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the
+    # profiler on itself, so the committed measurement of the same build is attached.
+    for tname in ("r2_traffic.json", "r1_traffic.json"):
+        tpath = os.path.join(REPO, "profiles", tname)
+        if a.prec == "bf16" and H == 512 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            result["roofline"]["traffic"] = tj["hbm_bytes"]
+            result["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{tname})"
+            result["roofline"]["algorithmic_bytes_per_launch"] = tj["algorithmic_bytes"]
+            break
 
     sel = ref = None
-    if not a.no_cpu_baseline:
-        base, sel, ref = cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, a.cpu_rays)
+    if world == 1 and not a.no_cpu_baseline:
+        base, sel, ref = cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, a.cpu_rays, f"the same {H}x{W} frame")
         result["cpu_baseline"] = base
         # parity of the measured configuration on the CPU-baseline sample
         got = r.render_rays(rb[sel.to(dev)], skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance)
@@ -209,32 +337,44 @@ def main():
                             "max_abs": err, "rgb_rmse": mse ** 0.5,
                             "rgb_psnr_db": -10 * np.log10(max(mse, 1e-30))}
 
-    if not a.no_modes and world == 1:
+    if world == 1 and not a.no_modes:
         modes = {}
-        for name in ("fp16", "bf16x3", "fp32"):
-            if name == a.prec:
+        for name in ("fp16c", "fp16", "bf16x3", "fp32"):
+            if name == a.prec or name not in PREC_BY_NAME:
                 continue
             r.set_precision(name)
-            steps = 3 if name == "fp16" else 1
-            r.render_rays(rb[: n // 8], skts, cyl, want_alpha=False)
-            torch.cuda.synchronize(dev)
-            r.profile_enable(True); r.profile_read()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                r.render_rays(rb, skts, cyl, want_alpha=False)
-            torch.cuda.synchronize(dev)
-            mdt = time.perf_counter() - t0
-            ml, mms, mpts = r.profile_read()
-            r.profile_enable(False)
-            m = {"rays_per_s": n * steps / mdt, "ms_per_frame": mdt / steps * 1e3,
-                 "kernel_tflops": mpts * flops_pt / (mms * 1e-3) / 1e12, "peak_tflops": PEAK_TFLOPS[name]}
-            m["frac"] = m["kernel_tflops"] / m["peak_tflops"]
+            steps = 1 if name == "fp32" else 3
+            rs, msf, tf, _ = timed_rays(r, dev, rb, skts, cyl, cfg, steps)
+            m = {"rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "peak_tflops": PEAK_TFLOPS[name],
+                 "frac": tf / PEAK_TFLOPS[name]}
             if sel is not None:
                 got = r.render_rays(rb[sel.to(dev)], skts, cyl)
                 m["max_abs_rgb_vs_oracle"] = float((got["rgb_map"].cpu() - ref["rgb_map"]).abs().max())
+                m["max_abs_acc_vs_oracle"] = float((got["acc_map"].cpu() - ref["acc_map"]).abs().max())
             modes[name] = m
         r.set_precision(a.prec)
         result["modes"] = modes
+
+    if world == 1 and not a.no_extras:
+        result["host_to_host"] = host_to_host(caster, cfg, dev, H, W)
+        # BASELINE config 4: h36m (128 coarse + 16 importance samples, 16-d frame codes), one full frame
+        c4 = h36m_config()
+        m4 = syn.make_model(c4, 0)
+        cast4 = HipRayCaster.from_weights(c4, *m4, device=dev, precision=a.prec)
+        cams = (torch.arange(n, device=dev) % c4.n_framecodes).float()
+        rs, msf, tf, kms = timed_rays(cast4.renderer, dev, rb, skts, cyl, c4, 2, cams=cams)
+        result["workloads"] = {"h36m_512": {
+            "workload": f"h36m config, {H}x{W} full frame ({n} rays), {c4.n_samples}+{c4.n_importance} samples/ray = "
+                        f"{c4.evals_per_ray()} MLP evals/ray, per-ray frame-code index, view layer K = {c4.ch_view_in}",
+            "rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / peak, "avg_launch_ms": kms,
+            "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
+        cast4.renderer.close()
+        if not a.no_cpu_baseline:   # BASELINE config 1: 128x128, 32 coarse (+16) samples per ray
+            c1 = surreal_config(n_samples=32)
+            _, _, _, rb1, sk1, cy1 = full_frame_rays(128, 128, "cpu")
+            b1, _, _ = cpu_baseline(rb1, sk1, cy1, c1, model, min(a.cpu_rays, 8192), "the 128x128 frame of config 1 (32+16 samples/ray)")
+            rs1, msf1, _, _ = timed_rays(r, dev, rb1.to(dev), skts, cyl, c1, 3)
+            result["cpu_baselines"] = {"config1_128x128x32": dict(b1, gpu_rays_per_s=rs1, gpu_ms_per_frame=msf1)}
 
     print(json.dumps(result))
     if world > 1:

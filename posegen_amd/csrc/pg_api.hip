@@ -247,7 +247,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.dbg_stage = dbg_stage;
     const bool sa = is_shape_a(prec);
     const int pts = sa ? pg_eval16_points_per_pass() : pg_eval32_points_per_pass();
-    if (S < pts / (MAXR - 1))
+    if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
         return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
     a.n_iters = (int)iters;

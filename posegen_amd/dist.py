@@ -51,28 +51,34 @@ def gather_frames(local: torch.Tensor, frame_ids: Sequence[int], parts: List[Lis
 
 def render_path_distributed(render_poses, hwf, chunk, render_kwargs, group=None, **kw):
     """`render_path` over all ranks of the process group: every rank renders its share of
-    the frames and every rank returns all frames.  Signature of render.render_path."""
+    the frames and every rank returns all frames.  Signature of render.render_path.
+
+    The shares are balanced by the ray count of each frame's box (no rays are generated for
+    that); a rank whose share is empty (fewer frames than ranks) renders nothing but still
+    takes part in the all-gather; the gathered maps stay on the device until the one final
+    device->host copy of the assembled frames."""
     import torch.distributed as dist
-    from .rays import kp_to_valid_rays
-    from .render import render_path, _caster_device
+    from .rays import kp_to_boxes
+    from .render import render_frames_device
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     H, W, focal = hwf
+    if not (isinstance(H, (int, np.integer)) and isinstance(W, (int, np.integer))):
+        raise ValueError("render_path_distributed needs one frame size (scalar H, W) for the gather")
     rf = kw.get("render_factor", 0)
-    Hs, Ws = (H // rf, W // rf) if rf else (H, W)
+    centers = kw.get("centers")
+    Hs, Ws = (int(H) // rf, int(W) // rf) if rf else (int(H), int(W))
     fs = focal if not rf else (focal / rf if isinstance(focal, float) else focal.copy() / rf)
-    _, vids, _, _ = kp_to_valid_rays(render_poses, Hs, Ws, fs, kps=kw.get("kp"), cylinder_params=kw.get("cyls"),
-                                     ext_scale=kw.get("ext_scale", 0.00035), centers=kw.get("centers"))
-    parts = partition_frames([len(v) for v in vids], world)
+    if rf and centers is not None:
+        centers = centers / rf if isinstance(focal, float) else centers.copy() / rf
+    boxes = kp_to_boxes(render_poses, Hs, Ws, fs, kps=kw.get("kp"), cylinder_params=kw.get("cyls"),
+                        ext_scale=kw.get("ext_scale", 0.00035), centers=centers)
+    parts = partition_frames([len(g[0]) for g in boxes[2]], world)
     mine = parts[rank]
-    rgbs, disps, accs, valid_idxs, bboxes = render_path(render_poses, hwf, chunk, render_kwargs, ret_acc=True,
-                                                        frame_ids=mine, **{k: v for k, v in kw.items() if k != "ret_acc"})
-    _, dev = _caster_device(render_kwargs["ray_caster"])
-    F = len(render_poses)
-    if len(mine) > 0:
-        packed = torch.cat([torch.as_tensor(rgbs), torch.as_tensor(disps), torch.as_tensor(accs)], -1)
-    else:
-        packed = torch.zeros((0, Hs, Ws, 5))
-    if dist.get_backend(group) == "nccl":
-        packed = packed.to(dev)
-    full = gather_frames(packed.float(), mine, parts, F, group).cpu().numpy()
-    return full[..., 0:3], full[..., 3:4], full[..., 4:5], valid_idxs, bboxes
+    keep = ("centers", "kp", "skts", "cyls", "bg_imgs", "bg_indices", "cams", "render_factor", "white_bkgd", "ext_scale")
+    rgbs, disps, accs, valid_idxs, bboxes = render_frames_device(
+        render_poses, hwf, chunk, render_kwargs, frame_ids=mine, boxes=boxes,
+        **{k: v for k, v in kw.items() if k in keep})
+    packed = torch.cat([rgbs, disps, accs], -1).float()          # [f_local, H, W, 5] on the render device
+    full = gather_frames(packed, mine, parts, len(render_poses), group).cpu().numpy()
+    accs_out = full[..., 4:5] if kw.get("ret_acc", True) else []
+    return full[..., 0:3], full[..., 3:4], accs_out, valid_idxs, bboxes

@@ -431,6 +431,10 @@ class HipRayCaster:
             raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
         if skts is None or cyls is None:
             raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
+        # One call = one nanmean group, like get_near_far_in_cylinder on the reference's ray_batch
+        # (ray_utils.py:292-344): only batchify_rays / render_path split a frame into `chunk` groups.
+        if not getattr(self, "_grouped_call", False):
+            self.renderer.set_chunk(max(int(ray_batch.shape[0]), 1))
         return self.renderer.render_rays(ray_batch, skts, cyls, cams=cams, n_samples=N_samples,
                                          n_importance=N_importance, lindisp=bool(lindisp),
                                          want_alpha=want_alpha, extras=extras)
@@ -460,6 +464,8 @@ def load_raycaster(ckpt_path: str, cfg: RenderConfig, device="cuda:0", precision
     loop (run_gan.py:135-165, 2290-2330); here a repeated call returns the caster whose packed
     weights are already resident on the device."""
     import os
+    if isinstance(precision, str):
+        precision = PREC_BY_NAME[precision]
     st = os.stat(ckpt_path)
     key = (os.path.abspath(ckpt_path), st.st_mtime_ns, st.st_size, repr(cfg), str(device), int(precision))
     kw = _RAYCASTER_CACHE.get(key)

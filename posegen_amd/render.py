@@ -29,7 +29,12 @@ def batchify_rays(rays_flat, chunk=1024 * 32, ray_caster=None, **kwargs):
     """All rays in ONE call; `chunk` only sets the nanmean group size (trainer.py:64-81)."""
     r, dev = _caster_device(ray_caster)
     r.set_chunk(int(chunk))
-    return ray_caster(rays_flat.to(dev), **kwargs)
+    inner = getattr(ray_caster, "module", ray_caster)
+    inner._grouped_call = True          # keep the `chunk` groups: forward() alone is one group per call
+    try:
+        return ray_caster(rays_flat.to(dev), **kwargs)
+    finally:
+        inner._grouped_call = False
 
 
 def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1., center=None,
@@ -63,15 +68,13 @@ def _pick(x, i):
 
 
 @torch.no_grad()
-def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, skts=None, cyls=None,
-                bones=None, gt_imgs=None, bg_imgs=None, bg_indices=None, cams=None, subject_idxs=None,
-                render_factor=0, white_bkgd=False, ret_acc=False, ext_scale=0.00035, base_bg=1.0,
-                frame_ids: Optional[list] = None):
-    """Render frames; returns (rgbs [F,H,W,3], disps [F,H,W,1], accs, valid_idxs, bboxes).
-
-    `frame_ids` (extension) restricts rendering to a subset of frames (multi-GPU
-    partition); the returned arrays then hold those frames in the given order.
-    """
+def render_frames_device(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, skts=None, cyls=None,
+                         bg_imgs=None, bg_indices=None, cams=None, render_factor=0, white_bkgd=False,
+                         ext_scale=0.00035, frame_ids: Optional[list] = None, boxes=None):
+    """The frame loop of `render_path` with its results left on the device:
+    (rgbs [f,H,W,3], disps [f,H,W,1], accs [f,H,W,1] device tensors, valid_idxs, bboxes).
+    `frame_ids` restricts rendering to a subset of the frames (multi-GPU partition; an empty
+    list returns empty [0,H,W,C] stacks); `boxes` = a kp_to_boxes result computed by the caller."""
     H, W, focal = hwf
     if render_factor != 0:
         H, W = H // render_factor, W // render_factor
@@ -83,8 +86,8 @@ def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, 
     r, dev = _caster_device(render_kwargs["ray_caster"])
     # Boxes on the host (float64 numpy like the reference); rays, rendering and the scatter into
     # the background frame on the device (pg_render_frame): no per-frame meshgrid, no ray copies.
-    cyls, bboxes, grids = kp_to_boxes(render_poses, H, W, focal, kps=kp, cylinder_params=cyls,
-                                      ext_scale=ext_scale, centers=centers)
+    cyls, bboxes, grids = boxes if boxes is not None else kp_to_boxes(
+        render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale, centers=centers)
     valid_idxs = [rows * w + cols for rows, cols, _, w, _, _, _ in grids]
     ids = list(range(len(render_poses))) if frame_ids is None else list(frame_ids)
     rgbs, disps, accs = [], [], []
@@ -107,8 +110,29 @@ def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, 
         rgbs.append(rgb_img)
         disps.append(disp_img)
         accs.append(acc_img)
-    rgbs = torch.stack(rgbs).cpu().numpy()
-    disps = torch.stack(disps).cpu().numpy()
-    disps[np.isnan(disps)] = 0.
-    accs = torch.stack(accs).cpu().numpy() if ret_acc else []
+    if not ids:
+        if not (isinstance(H, int) and isinstance(W, int)):
+            raise ValueError("an empty frame share needs scalar H, W to shape its (empty) result")
+        e = lambda c: torch.zeros((0, H, W, c), device=dev)
+        return e(3), e(1), e(1), valid_idxs, bboxes
+    rgbs, disps, accs = torch.stack(rgbs), torch.stack(disps), torch.stack(accs)
+    disps = torch.nan_to_num(disps, nan=0.0, posinf=float("inf"), neginf=float("-inf"))   # run_nerf.py:142-143
     return rgbs, disps, accs, valid_idxs, bboxes
+
+
+@torch.no_grad()
+def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, skts=None, cyls=None,
+                bones=None, gt_imgs=None, bg_imgs=None, bg_indices=None, cams=None, subject_idxs=None,
+                render_factor=0, white_bkgd=False, ret_acc=False, ext_scale=0.00035, base_bg=1.0,
+                frame_ids: Optional[list] = None):
+    """Render frames; returns (rgbs [F,H,W,3], disps [F,H,W,1], accs, valid_idxs, bboxes) as the
+    reference does: numpy arrays on the host (run_nerf.py:27-147).
+
+    `frame_ids` (extension) restricts rendering to a subset of frames (multi-GPU
+    partition); the returned arrays then hold those frames in the given order.
+    """
+    rgbs, disps, accs, valid_idxs, bboxes = render_frames_device(
+        render_poses, hwf, chunk, render_kwargs, centers=centers, kp=kp, skts=skts, cyls=cyls, bg_imgs=bg_imgs,
+        bg_indices=bg_indices, cams=cams, render_factor=render_factor, white_bkgd=white_bkgd, ext_scale=ext_scale,
+        frame_ids=frame_ids)
+    return (rgbs.cpu().numpy(), disps.cpu().numpy(), accs.cpu().numpy() if ret_acc else [], valid_idxs, bboxes)

@@ -118,8 +118,59 @@ open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ok_{rank}"), "w"
 
 
 def test_gather_frames_gloo_world2(tmp_path):
+    _run_world2(tmp_path, _GLOO_WORKER)
+
+
+_GLOO_RENDER_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from posegen_amd import synthetic as syn
+from posegen_amd.dist import render_path_distributed
+from posegen_amd.render import render_path
+
+class StubRenderer:                       # stands in for HipRenderer: a frame = f(box, pose, camera)
+    device = torch.device("cpu")
+    calls = 0
+    def set_chunk(self, c): self.chunk = c
+    def render_frame(self, H, W, focal, c2w, box, skts, cyl, center=None, cam=None, **kw):
+        StubRenderer.calls += 1
+        (tlx, tly), (brx, bry) = box
+        v = float(torch.as_tensor(skts).sum()) + float(np.asarray(c2w).sum())
+        rgb = torch.full((H, W, 3), 1.0); disp = torch.zeros(H, W, 1); acc = torch.zeros(H, W, 1)
+        rgb[tly:bry, tlx:brx] = v % 1.0
+        disp[tly:bry, tlx:brx] = float("nan")      # empty rays: NaN disparity -> 0 (run_nerf.py:142-143)
+        acc[tly:bry, tlx:brx] = (brx - tlx) / W
+        return rgb, disp, acc
+class StubCaster:
+    renderer = StubRenderer()
+    module = property(lambda self: self)
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+H = W = 64
+for F in (1, 3):                          # F = 1 < world: rank 1 owns nothing and must still gather
+    _, kps, skts = syn.make_pose(F, 3)
+    c2ws, focals = syn.make_camera(F, H, W)
+    kw = dict(kp=torch.tensor(kps), skts=torch.tensor(skts), white_bkgd=True, ext_scale=0.001, ret_acc=True)
+    rk = {"ray_caster": StubCaster(), "N_samples": 64, "N_importance": 16}
+    want = render_path(torch.tensor(c2ws), (H, W, focals), 4096, rk, **kw)
+    before = StubRenderer.calls
+    got = render_path_distributed(torch.tensor(c2ws), (H, W, focals), 4096, rk, **kw)
+    mine = StubRenderer.calls - before
+    for a, b in zip(want[:3], got[:3]):
+        assert a.shape == b.shape and np.array_equal(a, b), (rank, F)
+    assert np.array_equal(np.array(got[4]), np.array(want[4]))
+    n = torch.tensor([mine]); dist.all_reduce(n)
+    assert int(n) == F, "every frame rendered exactly once across the ranks"
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ok_{rank}"), "w").write("ok")
+"""
+
+
+def _run_world2(tmp_path, source):
     script = tmp_path / "worker.py"
-    script.write_text(_GLOO_WORKER)
+    script.write_text(source)
     env = dict(os.environ, OMP_NUM_THREADS="1")
     for attempt in range(3):        # the probed port can be taken again before torchrun binds it
         with socket.socket() as s:
@@ -132,6 +183,33 @@ def test_gather_frames_gloo_world2(tmp_path):
             break
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()      # (stdout of the ranks interleaves)
+
+
+def test_render_path_distributed_gloo_world2_fewer_frames_than_ranks(tmp_path):
+    """render_path_distributed == render_path on every rank, including F = 1 on two ranks (the
+    rank with an empty share must reach the all-gather instead of dying in torch.stack([]))."""
+    _run_world2(tmp_path, _GLOO_RENDER_WORKER)
+
+
+def test_bench_launches_itself_for_n_gpus_dry_run():
+    """`python bench.py --gpus 2` with no rendezvous in the environment starts its own two
+    ranks (as a child process) and relays rank 0's single JSON line; --dry-run swaps the renderer
+    for a stub and RCCL for gloo, everything else (barrier, max over ranks, all-gather) is real."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--res", "64", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["metric"].startswith("rendered rays/sec") and j["unit"] == "rays/s"
+    assert abs(j["value"] - 2 * 64 * 64 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # a child failure is an error exit, not a silent empty line
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--prec", "nope", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and not bad.stdout.strip()
 
 
 def test_inline_asm_ring_reads_are_not_touched_by_the_compiler():

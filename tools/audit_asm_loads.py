@@ -1,53 +1,81 @@
 #!/usr/bin/env python3
-"""Audit of the hand-issued ring reads in the compiled eval16 kernels (guide 5.7): between
-an inline-asm `ds_read_b128 vDST, vA offset:N*1024` and the MFMA that consumes vDST there must
-be (a) an inline-asm s_waitcnt and (b) no other instruction touching vDST (a compiler copy or
-spill of a register whose load has not landed would read garbage); and (c) no scalar memory load
-may be issued while a hand-issued read is in flight: SMEM shares lgkmcnt with LDS and returns out
-of order, so a counted lgkmcnt wait would no longer prove that the LDS read has landed.
-usage: audit_asm_loads.py kernel.s"""
-import re, sys
+"""Audit of the hand-issued ring reads in the compiled fused kernels (guide 5.7).
+
+The kernels issue their weight-ring reads by inline asm (`ds_read_b128 vDST, vA offset:N*1024`)
+and retire them with COUNTED `s_waitcnt lgkmcnt(N)`; hipcc sees neither.  For every such read
+the compiled code must satisfy, between its issue and the MFMA that consumes vDST:
+  (a) a wait that really covers it: LDS operations return in issue order, so `lgkmcnt(N)`
+      retires every LGKM operation except the N youngest -- the audit keeps the in-order queue
+      of ALL LDS operations of the wave (hand-issued and compiler-issued, reads and writes)
+      and fails when the consuming MFMA finds its read still among the unretired ones;
+  (b) no other instruction touches vDST (a compiler copy or spill of a register whose load has
+      not landed would read garbage);
+  (c) no scalar memory load is issued while a hand-issued read is in flight: SMEM shares
+      lgkmcnt with LDS and returns out of order, so a counted wait would prove nothing.
+usage: audit_asm_loads.py kernel.s [kernel-name-regex]"""
+import re
+import sys
+
+KERNEL_RE = sys.argv[2] if len(sys.argv) > 2 else r'_ZN3pgd\d+eval\w*_kernel'
 txt = open(sys.argv[1]).read()
-kernels = re.split(r'\n(?=_ZN3pgd\d+eval16[sw]?_kernel)', txt)
+kernels = re.split(r'\n(?=' + KERNEL_RE + ')', txt)
+HAND = re.compile(r'ds_read_b128 v\[(\d+):(\d+)\], v\d+ offset:\d+\*1024')
 bad = 0
+
+
+def vregs(t):
+    used = set()
+    for a, b in re.findall(r'\bv\[(\d+):(\d+)\]', t):
+        used |= set(range(int(a), int(b) + 1))
+    used |= {int(x) for x in re.findall(r'(?<![\w\[])v(\d+)\b', t)}
+    return used
+
+
 for k in kernels:
-    if not re.match(r'_ZN3pgd\d+eval16[sw]?_kernel', k):
+    if not re.match(KERNEL_RE, k):
         continue
     name = k.split(':', 1)[0]
-    lines = k.split('\n')
-    pending = {}          # first reg -> (line no, set(regs), waited?)
+    queue = []            # in-order LGKM operations in flight: None (compiler's) or dict (hand-issued)
     n_loads = 0
-    for i, ln in enumerate(lines):
-        t = ln.strip()
-        if not t or t.startswith(';') and 'ASM' not in t:
+    for i, ln in enumerate(k.split('\n')):
+        t = ln.split(';')[0].strip()
+        if not t or t.endswith(':') or t.startswith('.'):
             continue
-        m = re.match(r'ds_read_b128 v\[(\d+):(\d+)\], v\d+ offset:\d+\*1024', t)
+        pending = [q for q in queue if q is not None]
+        m = HAND.match(t)
         if m:
             regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
-            for key, (l0, r0, w0) in list(pending.items()):
-                if r0 & regs:
-                    print(f"{name}: line {i}: load overwrites still-pending {sorted(r0)} from line {l0}"); bad += 1
-            pending[int(m.group(1))] = (i, regs, False)
+            for q in pending:
+                if q['regs'] & regs:
+                    print(f"{name}: line {i}: load overwrites still-pending {sorted(q['regs'])} from line {q['line']}")
+                    bad += 1
+            queue.append({'line': i, 'regs': regs})
             n_loads += 1
             continue
-        if re.match(r's_(buffer_)?load_', t) and pending:
-            print(f"{name}: line {i}: [{t}] scalar load while {len(pending)} hand-issued LDS reads are in flight"); bad += 1
-        if t.startswith('s_waitcnt lgkmcnt'):
-            for key in pending:
-                l0, r0, _ = pending[key]
-                pending[key] = (l0, r0, True)
+        if re.match(r's_(buffer_)?load_', t):
+            if pending:
+                print(f"{name}: line {i}: [{t}] scalar load while {len(pending)} hand-issued LDS reads are in flight")
+                bad += 1
+            queue.append(None)
             continue
-        used = set()
-        for a, b in re.findall(r'v\[(\d+):(\d+)\]', t):
-            used |= set(range(int(a), int(b) + 1))
-        used |= {int(x) for x in re.findall(r'\bv(\d+)\b', t)}
-        for key, (l0, r0, waited) in list(pending.items()):
-            if r0 & used:
-                if t.startswith('v_mfma') and waited:
-                    del pending[key]
-                else:
-                    print(f"{name}: line {i}: [{t}] touches {sorted(r0)} of the load at line {l0} (waited={waited})"); bad += 1
-                    del pending[key]
-    print(f"{name[:60]}: {n_loads} asm loads audited")
+        if t.startswith('ds_'):                       # compiler-issued LDS operation
+            queue.append(None)
+            # fall through: it may also touch a pending register (checked below)
+        if t.startswith('s_waitcnt'):
+            m = re.search(r'lgkmcnt\((\d+)\)', t)
+            if m:
+                keep = int(m.group(1))
+                queue = queue[len(queue) - keep:] if keep else []
+            continue
+        if t.startswith('s_barrier') or t.startswith('s_endpgm'):
+            continue
+        used = vregs(t)
+        for q in pending:
+            if q['regs'] & used:
+                print(f"{name}: line {i}: [{t}] touches {sorted(q['regs'])} of the load at line {q['line']}, "
+                      f"which no s_waitcnt has retired ({len(queue) - queue.index(q) - 1} younger LGKM operations)")
+                bad += 1
+                queue.remove(q)
+    print(f"{name[:70]}: {n_loads} asm loads audited")
 print("AUDIT", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
