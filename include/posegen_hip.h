@@ -187,8 +187,9 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
  * dbg (optional, [n*S,256] floats) receives one intermediate activation per point,
  * selected by dbg_stage: 0 = pre-activation of density layer 0; 1..7 = output of density
  * layer 1..7 (post-ReLU); 8 = feature_linear output; 9 = view layer output (128 used);
- * 10 = view cutoff weights wd (24 used).  Stages > 0 are only honoured by the fp32-grade
- * kernels (PG_PREC_FP32 / *X3). */
+ * 10 = view cutoff weights wd (24 used); 11 = the first 16 units of view-layer input values as
+ * the MFMA sees them; 12..17 = floats 64(s-12).. of the lane half's view table as found in LDS at the
+ * end of the pass.  Stages > 0 are only honoured by the fp32-grade kernels (PG_PREC_FP32 / *X3). */
 int pg_stage_eval(pg_handle* h, void* stream, int which_net, int64_t n, int n_samples,
                   const float* ray_batch, const float* z, const float* skts,
                   int64_t pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage);

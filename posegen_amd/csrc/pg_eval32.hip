@@ -279,6 +279,12 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         hidden_segment<P, 1>(&accr, st, C_RGB, act, VW / 2);
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
+        if (a.dbg && a.dbg_stage >= 12 && a.dbg_stage < 12 + DSEQ / 64 + 1 && valid) {
+            // the view table as this lane finds it in LDS at the END of the pass: 64 values of its half
+            const volatile float* tv = slot + SLOT_DTAB + h * DSEQ + (a.dbg_stage - 12) * 64;
+            for (int e = 0; e < 64; ++e)
+                if ((a.dbg_stage - 12) * 64 + e < DSEQ) a.dbg[gp * W + h * 64 + e] = tv[e];
+        }
     }
     st.drain();
 }
