@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 /* error codes */
 #define PG_OK 0
@@ -41,7 +41,11 @@ extern "C" {
 #define PG_PREC_BF16X3 2    /* split bf16: hi*hi + hi*lo + lo*hi */
 #define PG_PREC_FP16 3      /* fp16 x fp16 */
 #define PG_PREC_FP16X3 4    /* split fp16: hi*hi + hi*lo + lo*hi */
-#define PG_PREC_COUNT 5
+#define PG_PREC_FP16C 5     /* compensated fp16: two fp16 products per MAC into one fp32 accumulator,
+                             * 128 f16(W/129) * f16(x) + f16(W1 + 129 (W/129 - W1)) * f16(x1 + 129 (x - x1)):
+                             * the cross terms W_lo x and W x_lo are recovered to 2^-7 of their size, so the
+                             * operand rounding of plain fp16 drops ~30x (<= 1e-5 on rgb/acc) */
+#define PG_PREC_COUNT 6
 
 /* flags of pg_render_rays */
 #define PG_FLAG_LINDISP 1   /* sample linearly in inverse depth (ray_utils.py:224-227) */

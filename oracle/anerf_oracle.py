@@ -87,7 +87,7 @@ class OracleConfig:
     tau_d: float = 20.0          # CutoffEmbedder.tau of embeddirs_fn
     density_scale: float = 1.0
     rgb_eps: float = 1e-3
-    # None = the reference's fp32.  'bf16' / 'fp16' / 'bf16x3' / 'fp16x3' EMULATE the MFMA
+    # None = the reference's fp32.  'bf16' / 'fp16' / 'bf16x3' / 'fp16x3' / 'fp16c' EMULATE the MFMA
     # operand rounding of the HIP kernel's precision modes (operands rounded to the 16-bit
     # type, or split into hi+lo halves with the lo*lo term dropped; products exact, fp32
     # accumulate) so that layout bugs can be told from rounding.
@@ -371,6 +371,14 @@ def _linear(x, w, b, quant: Optional[str]):
     """F.linear with the operand rounding of the kernel's precision modes (see OracleConfig)."""
     if quant is None:
         return F.linear(x, w, b)
+    if quant == "fp16c":        # compensated fp16 (PG_PREC_FP16C): 128 w1 x1 + w2 x2, w = W / 129, one fp32 accumulator
+        s_ = 129.0
+        ws = (w.double() / s_)
+        w1 = ws.to(torch.float16).double()
+        w2 = (w1 + s_ * (ws - w1)).to(torch.float16).float()
+        x1 = x.to(torch.float16).float()
+        x2 = (x1 + s_ * (x - x1)).to(torch.float16).float()
+        return F.linear(x1, ((s_ - 1) * w1).float()) + F.linear(x2, w2) + (0 if b is None else b)
     xh, wh = _round16(x, quant), _round16(w, quant)
     if not quant.endswith("x3"):
         return F.linear(xh, wh, b)

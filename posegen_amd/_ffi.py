@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
-PG_ABI_VERSION = 2
+PG_ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):

@@ -526,7 +526,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
         // the fp32 / split kernels keep feature_linear and the direct view layer (13 + 4 out tiles)
         const int64_t direct = pgp::A::MFMA_PER_GROUP(fc) + (NT + 1 + NTV - (NTV + 1)) * pgp::A::HU;
         *mfma_per_group = sa ? (fact ? pgp::AF::MFMA_PER_GROUP(fc) : pgp::A::MFMA_PER_GROUP(fc))
-                             : (precision == PG_PREC_FP32 ? direct * 8 : (direct - NT * pgp::A::HU) * 3);
+                             : (precision == PG_PREC_FP32 ? direct * 8 : (direct - NT * pgp::A::HU) * (precision == PG_PREC_FP16C ? 2 : 3));
     }
     return PG_OK;
 }

@@ -4,6 +4,7 @@
 //   PG_PREC_FP32   : v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain (parity mode)
 //   PG_PREC_BF16X3 : every product as hi*hi + hi*lo + lo*hi of bf16 halves, fp32 accumulate
 //   PG_PREC_FP16X3 : the same with fp16 halves
+//   PG_PREC_FP16C  : compensated fp16, two products per MAC into one accumulator (PolC below)
 //
 // Workgroup = 4 waves (one per SIMD, up to 512 registers each): a wave keeps the fp32
 // activations of its 32 points (128 registers) plus the 8 out-tile accumulators of the
@@ -80,6 +81,45 @@ struct PolX3 {
         acc = Split<V>::mfma(alo, b.hi, acc);
         acc = Split<V>::mfma(ahi, b.lo, acc);
         acc = Split<V>::mfma(ahi, b.hi, acc);
+        return acc;
+    }
+};
+
+// Compensated fp16 (PG_PREC_FP16C): W x = (S-1) w1 x1 + w2 x2 with w = W / S, t1 = f16(t),
+// t2 = f16(t1 + S (t - t1)): the second product carries the first-order rounding terms of both
+// operands scaled by S, and (S-1) is a power of two, so both go into ONE fp32 accumulator.
+// Error per product (S-1) a b + (e_w x + w e_x) / S ~ 2^-17 of |w x| (plain fp16: 2^-11).
+struct PolC {
+    static constexpr bool FOLD = true;
+    static constexpr int UE = 8;
+    static constexpr int UBYTES = 2048;          // (S-1) w1 plane then w2 plane (pg_pack.cpp)
+    static constexpr int UPC = CHUNK_BYTES / UBYTES;
+    struct B { f16x8 x1, x2; };
+    static __device__ __forceinline__ float roundtrip(float x) {
+        const _Float16 h = (_Float16)x;
+        return (float)h + ((float)(_Float16)((float)h + (float)COMP_S * (x - (float)h)) - (float)h) / (float)COMP_S;
+    }
+    static __device__ __forceinline__ B prep(const float* x) {
+        B b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b.x1[j] = (_Float16)x[j];
+        // ONE conversion result must feed both the fragment and the residual x - x1: left visible,
+        // hipcc (-ffp-contract=on) forms the fragment with v_cvt_pk_f16_f32 from the fp32 value and
+        // the residual's copy with v_fma_mixlo_f16 from the exact product that produced x -- two
+        // roundings that disagree on ties, and the compensation then has the wrong sign (2^-11).
+        asm volatile("" : "+v"(b.x1));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float h = (float)b.x1[j];
+            b.x2[j] = (_Float16)(h + (float)COMP_S * (x[j] - h));
+        }
+        return b;
+    }
+    static __device__ __forceinline__ f32x16 mma(const uint8_t* u, const B& b, f32x16 acc) {
+        const f16x8 a1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(u));
+        const f16x8 a2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(u + 1024));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b.x1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b.x2, acc, 0, 0, 0);
         return acc;
     }
 };
@@ -320,6 +360,9 @@ extern "C" int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int frame
             break;
         case 4: /* PG_PREC_FP16X3 */
             e = framecode ? launch_eval32<PolX3<f16x8>, true>(*a, grid, s) : launch_eval32<PolX3<f16x8>, false>(*a, grid, s);
+            break;
+        case 5: /* PG_PREC_FP16C */
+            e = framecode ? launch_eval32<PolC, true>(*a, grid, s) : launch_eval32<PolC, false>(*a, grid, s);
             break;
         default: break;
     }

@@ -46,6 +46,7 @@ constexpr int NTV = VW / 32;     // 4
 constexpr int DEPTH = 8;
 constexpr int SKIP = 4;          // concat after layer 4 -> layer 5 has K = 432+256
 constexpr int FC_CH = 16;        // frame code channels (when enabled)
+constexpr int COMP_S = 129;      // compensated fp16 (PG_PREC_FP16C): t2 = f16(t1 + COMP_S (t - t1)), COMP_S - 1 a power of two
 
 #ifndef PG_CHUNK_KB
 #define PG_CHUNK_KB 32

@@ -125,7 +125,8 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A : SHAPE_B;
     const bool is_f32 = precision == PG_PREC_FP32;
     const bool is_bf = precision == PG_PREC_BF16 || precision == PG_PREC_BF16X3;
-    const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3;
+    const bool comp = precision == PG_PREC_FP16C;
+    const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3 || comp;     // two planes per unit
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
     if (fact && shape != SHAPE_A) return -3;
     if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
@@ -155,6 +156,17 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
                     if (is_f32) {
                         std::memcpy(&out[base + lane * 16 + e * 4], &wv, 4);
                     } else {
+                        if (comp) {
+                            // W = 129 w: plane 0 = 128 w1 (exact), plane 1 = f16(w1 + 129 (w - w1)), w1 = f16(w)
+                            const double wd = (double)wv / COMP_S;
+                            const uint16_t w1b = f32_to_f16((float)wd);
+                            const double w1 = f16_to_f32(w1b);
+                            const uint16_t p0 = f32_to_f16((float)((COMP_S - 1) * w1));
+                            const uint16_t p1 = f32_to_f16((float)(w1 + COMP_S * (wd - w1)));
+                            std::memcpy(&out[base + lane * 16 + e * 2], &p0, 2);
+                            std::memcpy(&out[base + 1024 + lane * 16 + e * 2], &p1, 2);
+                            continue;
+                        }
                         uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
                         std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
                         if (split) {

@@ -2,8 +2,9 @@
 committed golden vectors, on identical seeded inputs.  Run with `-m gpu` on an MI355X.
 
 Tolerances (north_star: "RGB/depth within 1e-4 of the reference"):
-  * fp32 mode and the split-operand mode bf16x3 (and the experimental fp16x3 when enabled
-    with POSEGEN_EXPERIMENTAL_X3=1): max |rgb/acc/disp error| <= 1e-4 vs the golden vectors
+  * fp32 mode, the compensated fp16 mode fp16c (two fp16 products per MAC) and the
+    split-operand mode bf16x3 (and the experimental fp16x3 when enabled with
+    POSEGEN_EXPERIMENTAL_X3=1): max |rgb/acc/disp error| <= 1e-4 vs the golden vectors
     captured from the reference itself
   * bf16 / fp16 single-pass modes cannot meet 1e-4 by construction (8 / 11 bit operand
     mantissa); they are held (a) to <= 5e-4 against an oracle that EMULATES their operand
@@ -17,7 +18,7 @@ import pytest
 import torch
 
 from oracle import anerf_oracle as orc
-from posegen_amd import PREC_BF16, PREC_BF16X3, PREC_FP16, PREC_FP16X3, PREC_FP32, PREC_NAMES
+from posegen_amd import PREC_BF16, PREC_BF16X3, PREC_FP16, PREC_FP16C, PREC_FP16X3, PREC_FP32, PREC_NAMES
 from tests.helpers import (cfg_from_golden, load_golden, model_for, oracle_cfg, oracle_render_rays,
                            torch_weights)
 
@@ -26,10 +27,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # fp16x3 is experimental (DESIGN.md "Known issues"): opt-in only
 X3 = os.environ.get("POSEGEN_EXPERIMENTAL_X3") == "1"
-EXACT_MODES = [PREC_FP32, PREC_BF16X3] + ([PREC_FP16X3] if X3 else [])
+EXACT_MODES = [PREC_FP32, PREC_FP16C, PREC_BF16X3] + ([PREC_FP16X3] if X3 else [])
 FAST_MODES = [PREC_BF16, PREC_FP16]
 # documented max-abs bounds vs the fp32 oracle: (rgb/acc, disp, alpha)
 BOUND = {PREC_FP32: (1e-4, 1e-4, 2e-4), PREC_BF16X3: (1e-4, 1e-4, 5e-4), PREC_FP16X3: (1e-4, 1e-4, 5e-4),
+         PREC_FP16C: (1e-4, 1e-4, 5e-4),
          PREC_FP16: (1e-3, 1e-3, 5e-3), PREC_BF16: (5e-3, 5e-3, 3e-2)}
 
 
@@ -112,7 +114,8 @@ def _oracle_stage(g, cfg, quant):
 # of the largest |raw| (the error against the unrounded oracle is the same for both forms).
 @pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 4e-2),
                                             (PREC_FP16, "fp16", 8e-3)]
-                         + [(PREC_BF16X3, None, 3e-3)] + ([(PREC_FP16X3, None, 2e-3)] if X3 else []))
+                         + [(PREC_BF16X3, None, 3e-3), (PREC_FP16C, "fp16c", 3e-4), (PREC_FP16C, None, 6e-4)]
+                         + ([(PREC_FP16X3, None, 2e-3)] if X3 else []))
 def test_stage_eval_coarse(casters, prec, quant, tol):
     """raw (rgb_raw, sigma_raw) and the layer-0 pre-activation of the coarse net."""
     g = load_golden("rays_surreal")

@@ -38,8 +38,20 @@ def split(t, mode):
     return terms
 
 
+def comp_split(t, s):
+    """fp16 pair (t1, t2) of the compensated product: t1 = fp16(t), t2 = fp16(t1 + s (t - t1))"""
+    t1 = t.to(torch.float16).to(torch.float32)
+    t2 = (t1 + s * (t - t1)).to(torch.float16).to(torch.float32)
+    return t1, t2
+
+
 def linear(x, w, b, mode):
     xm, wm = mode
+    if xm == "c":                    # compensated fp16: acc = (s-1) W1 x1 + W2 x2 with W = w / s, one accumulator
+        s_ = float(wm)
+        w1, w2 = comp_split(w.double().div(s_).float(), s_)
+        x1, x2 = comp_split(x, s_)
+        return F.linear(x1, (s_ - 1) * w1) + F.linear(x2, w2) + b
     xs, ws = split(x, xm), split(w, wm)
     out = None
     for i, xt in enumerate(xs):
@@ -103,18 +115,20 @@ def errs(ref, out):
 
 
 def main():
-    cases = sys.argv[1:] or ["rays_surreal", "rays_h36m", "rays_allhit", "rays_cfg1", "rays_coarse32"]
+    cases = [a for a in sys.argv[1:] if not a.startswith("--")] or ["rays_surreal", "rays_h36m", "rays_allhit", "rays_cfg1", "rays_coarse32"]
     H, HH, F32 = ("h", "h"), ("hh", "hh"), ("f32", "f32")
     recipes = {"fp16 all": uniform(H)}
-    for lay in LAYERS:                   # fp16 everywhere except one layer exact
+    for lay in (LAYERS if "--layers" in sys.argv else []):                   # fp16 everywhere except one layer exact
         r = uniform(H); r[lay] = F32
         recipes[f"fp16, {lay} exact"] = r
-    for lay in LAYERS:                   # exact everywhere except one layer fp16
+    for lay in (LAYERS if "--layers" in sys.argv else []):                   # exact everywhere except one layer fp16
         r = uniform(F32); r[lay] = H
         recipes[f"exact, {lay} fp16"] = r
     recipes["fp16 x:h w:hh all"] = uniform(("h", "hh"))
     recipes["fp16 x:hh w:h all"] = uniform(("hh", "h"))
     recipes["fp16 x3 all"] = uniform(HH)
+    for sc in (17, 33, 65, 129, 257):
+        recipes[f"fp16 compensated s={sc}"] = uniform(("c", str(sc)))
     for name, rec in recipes.items():
         line = []
         for c in cases:
