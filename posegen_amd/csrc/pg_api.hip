@@ -23,6 +23,8 @@ int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
 int pg_eval32_points_per_pass(void);
+int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream);
+int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
                             int S, int lindisp, float* near_far, float* z, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
@@ -145,6 +147,14 @@ bool use_fact(int prec, int S) {
     return allowed && is_shape_a(prec) && S >= FACT_MIN_S;
 }
 
+// PG_PREC_FP16C runs in its dedicated kernel (pg_evalc.hip) when a ray has >= COMP_MIN_S samples (then a
+// 128-point pass touches <= MAXR_C rays) and the points come from rays; otherwise (and with
+// POSEGEN_COMP_KERNEL=0, for A/B) in the k-major kernel of pg_eval32.hip, same arithmetic.
+bool use_comp_kernel(int prec, int S, bool points) {
+    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_COMP_KERNEL"); return !(e && e[0] == '0'); }();
+    return allowed && prec == PG_PREC_FP16C && !points && S >= COMP_MIN_S;
+}
+
 // MFMA shape of the factorised 16-bit kernel: 32x32x16 (pg_eval16.hip); POSEGEN_MFMA=16 selects
 // the 16x16x32 variant (pg_eval16s.hip), which measured the same wall time
 bool use_small_tiles() {
@@ -188,7 +198,7 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec][fact]), packed.size()));
     PG_HIP(h, hipMemcpy(ns.d_stream[prec][fact], packed.data(), packed.size(), hipMemcpyHostToDevice));
     ns.stream_bytes[prec][fact] = packed.size();
-    if (fact && !ns.d_vy[prec]) {
+    if (fact && is_shape_a(prec) && !ns.d_vy[prec]) {
         std::vector<uint8_t> vy;
         if (pgpack::pack_vy(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, vy) != 0)
             return fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
@@ -221,7 +231,8 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
                 const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
                 const float* points = nullptr) {
     const int prec = h->cfg.precision;
-    const bool fact = !points && use_fact(prec, S);      // explicit points: the direct kernel (q = R p + t)
+    const bool compk = use_comp_kernel(prec, S, points != nullptr);
+    const bool fact = compk || (!points && use_fact(prec, S));      // explicit points: the direct kernel (q = R p + t)
     int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const bool small = fact && use_small_tiles();
@@ -233,7 +244,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.rays = rays; a.z = z; a.pts = points; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
     a.wstream = small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
-    a.wy = fact ? ns.d_vy[prec] : nullptr;
+    a.wy = (fact && !compk) ? ns.d_vy[prec] : nullptr;
     a.bias = small ? ns.d_bias_s : ns.d_bias;
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
@@ -246,7 +257,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.tau_d = h->tau[1];
     a.dbg_stage = dbg_stage;
     const bool sa = is_shape_a(prec);
-    const int pts = sa ? pg_eval16_points_per_pass() : pg_eval32_points_per_pass();
+    const int pts = sa ? pg_eval16_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
     if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
         return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
@@ -266,6 +277,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     int e = small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : (fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
+          : compk ? pg_launch_evalc(&a, fc, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
         PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
@@ -519,13 +531,14 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     const bool sa = is_shape_a(precision);
     // 16-bit kernels: the factorised-view program (rays with >= 64 samples, the usual case)
     const bool fact = use_fact(precision, FACT_MIN_S);
+    const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
     if (stream_bytes)
-        *stream_bytes = (int64_t)(sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK)
+        *stream_bytes = (int64_t)(compk ? pgp::C::NCHUNK : sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK)
                                      : (precision == PG_PREC_FP32 ? pgp::B::NCHUNK : pgp::B::NCHUNK_FOLD)) * CHUNK_BYTES;
     if (mfma_per_group) {
         // the fp32 / split kernels keep feature_linear and the direct view layer (13 + 4 out tiles)
         const int64_t direct = pgp::A::MFMA_PER_GROUP(fc) + (NT + 1 + NTV - (NTV + 1)) * pgp::A::HU;
-        *mfma_per_group = sa ? (fact ? pgp::AF::MFMA_PER_GROUP(fc) : pgp::A::MFMA_PER_GROUP(fc))
+        *mfma_per_group = compk ? pgp::C::MFMA_PER_GROUP(fc) : sa ? (fact ? pgp::AF::MFMA_PER_GROUP(fc) : pgp::A::MFMA_PER_GROUP(fc))
                              : (precision == PG_PREC_FP32 ? direct * 8 : (direct - NT * pgp::A::HU) * (precision == PG_PREC_FP16C ? 2 : 3));
     }
     return PG_OK;

@@ -1,0 +1,397 @@
+// pg_evalc.hip -- fused bone-relative embedding + NeRF MLP in COMPENSATED fp16 (PG_PREC_FP16C):
+// the precision mode that meets the reference to <= 1e-4 at MFMA speed.  Shape C of pg_program.h.
+//
+// Replaces RayCaster.encode_inputs + run_network + NeRF.forward for one net (reference
+// core/raycasters.py:476-577, core/networks/nerf.py:90-148, core/encoders.py,
+// core/cutoff_embedder.py) on n*S points p = o + d*z, like pg_eval16.hip / pg_eval32.hip.
+//
+// Arithmetic.  Every product W x of the network is formed as
+//       (S-1) w1 x1 + w2 x2,      w = W / S,  t1 = f16(t),  t2 = f16(t1 + S (t - t1)),  S = 129
+// i.e. TWO v_mfma_f32_32x32x16_f16 per 16 k into ONE fp32 accumulator: the second product carries the
+// first-order rounding terms of both operands (w_lo x + w x_lo) scaled by S, and S-1 = 128 is a
+// power of two, so (S-1) w1 is exact and no second accumulator or epilogue is needed.  What is
+// left is (S-1) w_lo x_lo + (e_w x + w e_x)/S ~ 2^-17 |w x| per product (plain fp16: 2^-11;
+// tools/error_budget.py: rgb/acc within 4e-6 / 8e-6 of the fp32 oracle where fp16 has 2e-4).
+// The weight planes (S-1) w1 and w2 are formed on the host in double (pg_pack.cpp); the
+// activation pair is formed by conv_a / conv_b below from ONE v_cvt_pk_f16_f32 result.
+//
+// Shape.  Workgroup = 4 waves, one per SIMD, up to 512 registers; a wave owns 32 consecutive points
+// of the flattened [ray][sample] list.  Every segment is k-major: an input unit (8 values per lane
+// = one B-fragment pair) is multiplied into all out tiles of the layer.  The pre-activations of a
+// layer stay in the accumulators (the compiler keeps the two ping-pong sets of 8 tiles in AGPRs);
+// the NEXT unit's values are read back, ReLU'd and split into their fp16 pair in small steps that
+// are pinned between the MFMA pairs of the CURRENT unit (__builtin_amdgcn_sched_barrier), because
+// with one wave per SIMD nothing else would overlap that VALU work with the matrix pipe.
+// The weight stream is staged L2 -> LDS by LDS-DMA into the 3 x 32 KiB ring of pg_device.h and read
+// by hand-issued ds_read_b128 four units ahead with counted lgkmcnt waits (pg_eval16_common.h).
+#include "pg_eval16_common.h"
+
+namespace pgd {
+
+constexpr int NWAVE_C = 4;
+constexpr int NTHR_C = NWAVE_C * 64;
+constexpr int PTS_C = NWAVE_C * 32;
+using VC = f16x8;
+using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
+constexpr int NSC = 5;                        // register sets of the A pipe: reads issued 4 units = 2 pairs ahead
+constexpr int LDS_TOTAL_C = LDS_RTAB + MAXR_C * SLOTC_FLOATS * 4;
+static_assert(LDS_TOTAL_C <= 160 * 1024, "LDS budget of one CU");
+
+// ---- the fp16 pair of a value: x1 = f16(x) (RNE), x2 = f16(x1 + S (x - x1)) ---------------------
+// Both halves come from ONE conversion result: left to hipcc under -ffp-contract=on, the fragment
+// is formed by v_cvt_pk_f16_f32 from the fp32 value and the residual's copy by v_fma_mixlo_f16
+// from the exact product that produced the value -- two roundings that disagree on ties, after
+// which the compensation has the wrong sign (an error of a full fp16 ulp).
+// step A: two values -> their (optionally ReLU'd) fp32 values and the packed x1 pair
+template <bool RELU>
+__device__ __forceinline__ void conv_a(float a, float b, float& ra, float& rb, unsigned& h) {
+    if (RELU) {
+        asm("v_max_f32 %0, 0, %3\n\tv_max_f32 %1, 0, %4\n\tv_cvt_pk_f16_f32 %2, %0, %1"
+            : "=&v"(ra), "=&v"(rb), "=&v"(h) : "v"(a), "v"(b));
+    } else {
+        ra = a; rb = b;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+    }
+}
+// step B: d = x - x1 (exact), t = S d + x1, x2 pair = f16(t).  v_fma_mix_f32 reads the fp16 halves of
+// `h` directly.  The trailing s_nop 1 provides the wait states a VALU write needs before an MFMA may
+// read the register (hipcc pads nothing for inline asm).
+__device__ __forceinline__ unsigned conv_b(float ra, float rb, unsigned h, float s) {
+    unsigned x2;
+    float da, db;
+    asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %1, %6, %3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %2, %2, %6, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1"
+        : "=&v"(x2), "=&v"(da), "=&v"(db) : "v"(h), "v"(ra), "v"(rb), "s"(s));
+    return x2;
+}
+
+struct FragC { unsigned x1[4], x2[4]; };       // one input unit: 8 values per lane as the two MFMA B operands
+
+__device__ __forceinline__ VC frag_v(const unsigned* p) {
+    const u32x4 v = {p[0], p[1], p[2], p[3]};
+    return __builtin_bit_cast(VC, v);
+}
+
+// One k-major segment: NU input units against NO out tiles, `src(u, e)` = value e of unit u (indices
+// are compile-time constants after unrolling).  While the 2 NO MFMAs of unit u issue, unit u+1 is
+// read, (ReLU'd,) and split: 8 half steps (A and B of 4 value pairs) spread over the NO out tiles.
+// T = units (of 1 KiB) of the segment in the weight stream: 2 per (input unit, out tile).
+template <int NO, int NU, bool RELU, typename ST, typename SRC>
+__device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, float s129) {
+    constexpr int T = NU * NO * 2;
+    constexpr int PER = (8 + NO - 1) / NO;            // half steps per out tile
+    APipe<VC, NSC> p;
+    FragC cur, nxt;
+    float ra = 0.f, rb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                     // unit 0 up front
+        conv_a<RELU>(src(0, 2 * j), src(0, 2 * j + 1), ra, rb, cur.x1[j]);
+        cur.x2[j] = conv_b(ra, rb, cur.x1[j], s129);
+    }
+#pragma clang loop unroll(full)
+    for (int u = 0; u < NU; ++u) {
+#pragma clang loop unroll(full)
+        for (int o = 0; o < NO; ++o) {
+            const int L = (u * NO + o) * 2;
+            const VC a1 = next_a<VC, T, true, NSC>(p, st, L);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag_v(cur.x1), acc[o], 0, 0, 0);
+            const VC a2 = next_a<VC, T, true, NSC>(p, st, L + 1);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, frag_v(cur.x2), acc[o], 0, 0, 0);
+            if (u + 1 < NU) {
+#pragma clang loop unroll(full)
+                for (int hs = o * PER; hs < (o + 1) * PER && hs < 8; ++hs) {
+                    const int j = hs >> 1;
+                    if ((hs & 1) == 0) conv_a<RELU>(src(u + 1, 2 * j), src(u + 1, 2 * j + 1), ra, rb, nxt.x1[j]);
+                    else nxt.x2[j] = conv_b(ra, rb, nxt.x1[j], s129);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
+    }
+}
+
+// the 18 density-input values of one joint (joint_values_q of pg_device.h) for the compensated mode:
+// hardware transcendentals, but every octave's sin/cos straight from v_sin/v_cos (revolutions, exact
+// power-of-two argument scaling: 4.5e-7 absolute) instead of the angle-doubling chain, whose error
+// doubles per octave (5e-5 at the 7th: profiles/r2_trig_err.txt) -- too coarse for this mode
+__device__ __forceinline__ void joint_values_c(float qx, float qy, float qz, float tl, float cs, float* x) {
+    const float d2 = qx * qx + qy * qy + qz * qz;
+    const float rinv = __builtin_amdgcn_rsqf(fmaxf(d2, 1e-24f));
+    const float v = d2 * rinv;
+    const float w = cutoff_weight_fast(v, tl, cs);
+    const float rev = v * 0.15915494309189535f;
+    x[0] = v * w;
+#pragma unroll
+    for (int f = 0; f < LV; ++f) {
+        const float a = rev * (float)(1 << f);
+        x[1 + 2 * f] = __builtin_amdgcn_sinf(a) * w;
+        x[2 + 2 * f] = __builtin_amdgcn_cosf(a) * w;
+    }
+    x[15] = qx * rinv; x[16] = qy * rinv; x[17] = qz * rinv;
+}
+
+// one input unit already in registers against NO out tiles (x segments: no look-ahead conversion here)
+template <int NO, int T, typename ST>
+__device__ __forceinline__ void mma_row_c(f32x16* acc, APipe<VC, NSC>& p, ST& st, int uu, const FragC& b) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int L = (uu * NO + o) * 2;
+        const VC a1 = next_a<VC, T, true, NSC>(p, st, L);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag_v(b.x1), acc[o], 0, 0, 0);
+        const VC a2 = next_a<VC, T, true, NSC>(p, st, L + 1);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, frag_v(b.x2), acc[o], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ FragC frag_of(const float* x, float s129) {
+    FragC f;
+    float ra, rb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        conv_a<false>(x[2 * j], x[2 * j + 1], ra, rb, f.x1[j]);
+        f.x2[j] = conv_b(ra, rb, f.x1[j], s129);
+    }
+    return f;
+}
+
+// acc += W[:, x-columns] x: the 432-wide density input generated on the fly (X sequence of pg_layout.h).
+// The values of joint jj+1 are computed and split while the units of joint jj go through the matrix pipe.
+template <typename ST>
+__device__ __forceinline__ void x_segment_c(f32x16* acc, ST& st, const float* ab, float z, const float* cutb,
+                                            float tl, float s129) {
+    APipe<VC, NSC> p;
+    constexpr int T = pgp::C::XU * NT * 2;
+    auto values = [&](int jj, float* x) {
+        const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
+        joint_values_c(fmaf(z, hi.x, lo.x), fmaf(z, hi.y, lo.y), fmaf(z, hi.z, lo.z), tl, cutb[jj], x);
+    };
+    float xn[18];
+    values(0, xn);
+    FragC f0 = frag_of(xn, s129), f1 = frag_of(xn + 8, s129);
+    float lo[8];
+    lo[0] = xn[16]; lo[1] = xn[17];
+#pragma clang loop unroll(full)
+    for (int sb = 0; sb < 3; ++sb) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < 4; ++k) {
+            const int jj = 4 * sb + k;
+            const FragC c0 = f0, c1 = f1;
+            if (jj + 1 < JH) values(jj + 1, xn);                               // next joint: embedding math ...
+            mma_row_c<NT, T>(acc, p, st, sb * 9 + 2 * k, c0);
+            if (jj + 1 < JH) f0 = frag_of(xn, s129);                           // ... and its split, between this joint's rows
+            mma_row_c<NT, T>(acc, p, st, sb * 9 + 2 * k + 1, c1);
+            if (jj + 1 < JH) f1 = frag_of(xn + 8, s129);
+            if (k == 3) {
+                const FragC fl = frag_of(lo, s129);
+                mma_row_c<NT, T>(acc, p, st, sb * 9 + 8, fl);
+            }
+            if (jj + 1 < JH) { lo[2 * ((k + 1) & 3)] = xn[16]; lo[2 * ((k + 1) & 3) + 1] = xn[17]; }
+        }
+    }
+}
+
+// Per-ray LDS slots of this kernel (pg_layout.h SLOTC_*), one thread per (ray, joint):
+//   AB[j] = (a = R_j o + t_j, b = R_j d)                       (core/encoders.py:8-37)
+//   DTAB: e = normalize(b) per joint, rows (e, sin e, cos e, ..., sin 8e | cos 8e) in D-sequence order
+//   (encoders.py:172-193), accurate sincosf: the view table is per ray, its cost is nothing
+template <bool FC>
+__device__ __forceinline__ void ray_table_c(const EvalArgs& a, float* rt, int r0, int nr) {
+    for (int idx = threadIdx.x; idx < nr * J; idx += NTHR_C) {
+        const int rr = idx / J, j = idx - rr * J;
+        float* slot = rt + rr * SLOTC_FLOATS;
+        const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
+        const float4 ra = sk[0], rb = sk[1], rc = sk[2];
+        const float* ry = a.rays + (long long)(r0 + rr) * 11;
+        const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
+        float e[3];
+        e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
+        e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
+        e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
+        float4* ab = reinterpret_cast<float4*>(slot + SLOTC_AB + j * 8);
+        ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
+                            fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
+                            fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
+        ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
+        const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
+        const int h = j / JH, jj = j - h * JH;
+        float* tab = slot + SLOTC_DTAB + h * DSEQ;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ev = e[c] / den;
+            float s, co;
+            sincosf(ev, &s, &co);
+            float* m = tab + (jj * 3 + c) * 8;
+            m[0] = ev;
+#pragma unroll
+            for (int f = 0; f < LD; ++f) {
+                m[1 + 2 * f] = s;
+                if (f < LD - 1) m[2 + 2 * f] = co;
+                else tab[DSEQ_MAIN + jj * 3 + c] = co;
+                const float s2 = 2.0f * s * co;
+                co = (co - s) * (co + s);
+                s = s2;
+            }
+        }
+        if (jj == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tab[DSEQ_MAIN + JH * 3 + k] = 0.0f;
+        }
+    }
+    if (FC) {
+        for (int idx = threadIdx.x; idx < nr * FC_CH; idx += NTHR_C) {
+            const int rr = idx / FC_CH, k = idx - rr * FC_CH;
+            const float cf = a.cams ? a.cams[r0 + rr] : -1.0f;
+            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
+            rt[rr * SLOTC_FLOATS + SLOTC_CODE + k] = a.codes[ci * FC_CH + k];
+        }
+    }
+}
+
+template <bool FC>
+__global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
+    float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
+    float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, pt = lane & 31;
+    StreamC st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING), (uint32_t)lane * 16u};
+
+    for (int i = tid; i < BIAS_FLOATS; i += NTHR_C) bias[i] = a.bias[i];
+    // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
+    const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
+    if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    float s129 = (float)COMP_S;
+    asm volatile("" : "+s"(s129));              // one SGPR for the whole kernel, not a literal per use
+    st.start();
+
+    for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        const long long p0 = (long long)it * PTS_C;
+        const long long plast = min(p0 + PTS_C - 1, a.n_points - 1);
+        const int r0 = (int)(p0 / a.S);
+        const int nr = (int)(plast / a.S) - r0 + 1;
+        lds_barrier();                          // previous pass is done with the table
+        ray_table_c<FC>(a, rtab, r0, nr);
+        lds_barrier();
+
+        const long long gp = p0 + wave * 32 + pt;
+        const bool valid = gp < a.n_points;
+        const long long gpc = valid ? gp : a.n_points - 1;
+        const int myr = (int)(gpc / a.S) - r0;
+        const float* slot = rtab + myr * SLOTC_FLOATS;
+        const float* ab = opaque_ptr(slot + SLOTC_AB + JH * h * 8);
+        const float* cutv = opaque_ptr(cut + JH * h);
+        const float* cutd = opaque_ptr(cut + J + JH * h);
+        const float* tab = opaque_ptr(slot + SLOTC_DTAB + h * DSEQ);
+        const float zz = a.z[gpc];
+
+        f32x16 accA[NT], accB[NT];
+        // ---- layer 0: K = 432 generated on the fly ----
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + o, h);
+        x_segment_c(accA, st, ab, zz, cutv, tlv, s129);
+        if (a.dbg && a.dbg_stage == 0 && valid) {
+#pragma unroll
+            for (int o = 0; o < NT; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a.dbg[gp * W + 32 * o + rho(r, h)] = accA[o][r];
+        }
+        // ---- layers 1..4 (ping-pong between the two accumulator sets) ----
+        auto srcA = [&](int u, int e) { return accA[u >> 1][8 * (u & 1) + e]; };
+        auto srcB = [&](int u, int e) { return accB[u >> 1][8 * (u & 1) + e]; };
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 1 * NT + o, h);
+        segment_c<NT, HU, true>(accB, st, srcA, s129);
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 2 * NT + o, h);
+        segment_c<NT, HU, true>(accA, st, srcB, s129);
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 3 * NT + o, h);
+        segment_c<NT, HU, true>(accB, st, srcA, s129);
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 4 * NT + o, h);
+        segment_c<NT, HU, true>(accA, st, srcB, s129);
+        // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
+        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        x_segment_c(accB, st, ab, zz, cutv, tlv, s129);
+        // ---- layers 6, 7 ----
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 6 * NT + o, h);
+        segment_c<NT, HU, true>(accA, st, srcB, s129);
+#pragma unroll
+        for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 7 * NT + o, h);
+        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        if (a.dbg && a.dbg_stage == 7 && valid) {
+#pragma unroll
+            for (int i = 0; i < HSEQ; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(accB[i >> 4][i & 15], 0.0f);
+        }
+        // ---- sigma head and the view layer's trunk part in one segment of 1 + 4 out tiles: feature_linear
+        // has no activation and is folded into the view weights on the host (NetTensors::fold) ----
+        f32x16 av[NTV + 1];
+        av[0] = load_bias(bias, BT_ALPHA, h);
+#pragma unroll
+        for (int o = 0; o < NTV; ++o) av[1 + o] = load_bias(bias, BT_VIEWF + o, h);
+        segment_c<NTV + 1, HU, true>(av, st, srcB, s129);
+        const float sigma = av[0][0];
+        // ---- view directions: per-ray sin/cos table in LDS times the per-point cutoff weight ----
+        {
+            float wd[JH];
+#pragma unroll
+            for (int jj = 0; jj < JH; ++jj) {
+                const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
+                const float qx = fmaf(zz, hi.x, lo.x), qy = fmaf(zz, hi.y, lo.y), qz = fmaf(zz, hi.z, lo.z);
+                wd[jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+            }
+            if (a.dbg && a.dbg_stage == 10 && valid) {
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) a.dbg[gp * W + JH * h + jj] = wd[jj];
+            }
+            const float* code = slot + SLOTC_CODE + 8 * h;
+            auto srcD = [&](int u, int e) {
+                if (u == pgp::C::DU) return code[e];                   // frame code rides as one more unit
+                const int k = u < JH * 3 ? u / 3 : (8 * (u - JH * 3) + e) / 3;
+                return k < JH ? tab[u * 8 + e] * wd[k] : 0.0f;
+            };
+            segment_c<NTV, pgp::C::DU + (FC ? 1 : 0), false>(av + 1, st, srcD, s129);
+        }
+        if (a.dbg && a.dbg_stage == 9 && valid) {
+#pragma unroll
+            for (int i = 0; i < VW / 2; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(av[1 + (i >> 4)][i & 15], 0.0f);
+        }
+        // ---- rgb head ----
+        f32x16 accr = load_bias(bias, BT_RGB, h);
+        auto srcV = [&](int u, int e) { return av[1 + (u >> 1)][8 * (u & 1) + e]; };
+        segment_c<1, HU / 2, true>(&accr, st, srcV, s129);
+        if (valid && h == 0)
+            *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
+    }
+    st.drain();
+}
+
+template <bool FC>
+static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) {
+    auto k = evalc_kernel<FC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_C);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_C), LDS_TOTAL_C, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace pgd
+
+// needs S >= pgl::COMP_MIN_S, rays (no explicit points) and the shape-C stream (pg_pack.cpp)
+extern "C" int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return (int)(framecode ? pgd::launch_evalc<true>(*a, grid, s) : pgd::launch_evalc<false>(*a, grid, s));
+}
+
+extern "C" int pg_evalc_points_per_pass(void) { return pgd::PTS_C; }

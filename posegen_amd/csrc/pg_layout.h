@@ -141,6 +141,17 @@ PG_HD constexpr int vy_slot_joint(int u, int h, int e, bool fc) {
     return (fc && h == 0 && e == 4) ? JC : -1;
 }
 
+// ---- per-ray LDS slot of the compensated-fp16 kernel (pg_evalc.hip), floats -----------------
+// AB: per joint a = R_j o + t_j and b = R_j d (8 floats, 2 pads): q = a + z b; DTAB: the view table
+// of the classic slot (2 halves x DSEQ); CODE: the ray's frame code
+constexpr int SLOTC_AB = 0;                       // 24 x 8
+constexpr int SLOTC_DTAB = J * 8;                 // 192
+constexpr int SLOTC_CODE = SLOTC_DTAB + 2 * DSEQ; // 848
+constexpr int SLOTC_FLOATS = SLOTC_CODE + FC_CH;  // 864, multiple of 4
+constexpr int MAXR_C = 5;                         // rays overlapped by a 128-point pass when S >= 32
+constexpr int COMP_MIN_S = 32;
+static_assert(SLOTC_FLOATS % 4 == 0 && SLOTC_DTAB % 4 == 0 && SLOTC_CODE % 4 == 0, "LDS alignment");
+
 // ---- "small tile" layout of pg_eval16s.hip (v_mfma_f32_16x16x32, factorised view layer) ----
 // A = weights 16 out channels x 32 k, B = activations 32 k x 16 points, C = 16 x 16: lane
 // (g = lane>>4, col = lane&15) holds rows 4g..4g+3.  A wave still owns 32 points = two column

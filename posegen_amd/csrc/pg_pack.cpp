@@ -98,6 +98,19 @@ void NetTensors::fold() {
 static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false) {
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
+    if (shape == SHAPE_C) {         // compensated fp16 kernel (pg_evalc.hip): k-major everywhere, direct view layer
+        s.push_back({MAT_L0, NT, true, {{SEQ_X, XSEQ, 0}}});
+        for (int l = 1; l <= 4; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
+        s.push_back({MAT_L0 + 5, NT, true, {hid(CH_X)}});
+        s.push_back({MAT_L0 + 5, NT, true, {{SEQ_X, XSEQ, 0}}});
+        for (int l = 6; l <= 7; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
+        s.push_back({MAT_ALPHA_VIEWF, NTV + 1, true, {hid(0)}});
+        Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
+        if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
+        s.push_back(v);
+        s.push_back({MAT_RGB, 1, true, {{SEQ_H, VW / 2, 0}}});
+        return s;
+    }
     const bool km = (shape == SHAPE_B);
     s.push_back({MAT_L0, NT, true, {{SEQ_X, XSEQ, 0}}});
     for (int l = 1; l <= 4; ++l) s.push_back({MAT_L0 + l, NT, km, {hid(0)}});
@@ -122,13 +135,14 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
 
 int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base) {
-    const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A : SHAPE_B;
+    const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A
+                    : (precision == PG_PREC_FP16C && fact) ? SHAPE_C : SHAPE_B;
     const bool is_f32 = precision == PG_PREC_FP32;
     const bool is_bf = precision == PG_PREC_BF16 || precision == PG_PREC_BF16X3;
     const bool comp = precision == PG_PREC_FP16C;
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3 || comp;     // two planes per unit
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
-    if (fact && shape != SHAPE_A) return -3;
+    if (fact && shape == SHAPE_B) return -3;
     if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
@@ -180,7 +194,8 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         }
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK) : (split ? B::NCHUNK_FOLD : B::NCHUNK);
+    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK)
+                        : shape == SHAPE_C ? (size_t)C::NCHUNK : (split ? B::NCHUNK_FOLD : B::NCHUNK);
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
 }

@@ -9,7 +9,7 @@
 
 namespace pgpack {
 
-enum { SHAPE_A = 0, SHAPE_B = 1 };
+enum { SHAPE_A = 0, SHAPE_B = 1, SHAPE_C = 2 };
 
 // Borrowed host pointers to one net's tensors (reference checkpoint layout).
 struct NetTensors {
@@ -28,7 +28,8 @@ struct NetTensors {
 };
 
 // Packs the weight stream for `precision`; returns 0, or <0 on an internal layout error.
-// `fact` selects the factorised-view program of the 16-bit kernels (pg_program.h AF).
+// `fact` selects the factorised-view program of the 16-bit kernels (pg_program.h AF), or, for
+// PG_PREC_FP16C, the program of the dedicated kernel pg_evalc.hip (pg_program.h C).
 int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base = nullptr);
 void pack_bias(const NetTensors& t, std::vector<float>& out);

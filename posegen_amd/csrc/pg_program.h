@@ -101,4 +101,23 @@ constexpr int NCHUNK_FOLD = NCHUNK - CH_HID;
 static_assert(cdiv(DSEQ * NTV, VPC) == CH_VD, "view segment must take the same chunks with and without frame code");
 }  // namespace B
 
+// ---------------- shape C: compensated fp16 (pg_evalc.hip), k-major everywhere ----------------
+// A unit pair = 2 KiB: plane (S-1) w1 then plane w2 (pg_pack.cpp); one pair per (sequence unit, out tile).
+// [L0x][L1..L4][L5h][L5x][L6][L7][alpha | folded view trunk: 5 tiles][view directions (+code)][rgb]
+namespace C {
+constexpr int PPC = CHUNK_BYTES / 2048;       // unit pairs per chunk
+constexpr int XU = XSEQ / 8;                  // 27
+constexpr int HU = HSEQ / 8;                  // 16
+constexpr int DU = DSEQ / 8;                  // 41
+constexpr int CH_L0X = cdiv(XU * NT, PPC);    // 14
+constexpr int CH_HID = cdiv(HU * NT, PPC);    // 8
+constexpr int CH_AV = cdiv(HU * (NTV + 1), PPC);        // 5
+constexpr int CH_VD = cdiv((DU + 1) * NTV, PPC);        // 11
+constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AV + CH_VD + 1;
+static_assert(cdiv(DU * NTV, PPC) == CH_VD, "view segment must take the same chunks with and without frame code");
+constexpr int MFMA_PER_GROUP(bool fc) {
+    return 2 * (2 * XU * NT + 7 * HU * NT + HU * (NTV + 1) + (DU + (fc ? 1 : 0)) * NTV + HU / 2);
+}
+}  // namespace C
+
 }  // namespace pgp
