@@ -154,6 +154,9 @@ struct Stream {
     // builtin hipcc forms a 64-bit VGPR address (a v_lshl_add_u64) for every one of the ~224
     // pieces per pass.  m0 (the LDS destination) is not otherwise used by these kernels.
     __device__ __forceinline__ void piece(int i) const {
+#if defined(PG_ABL_NODMA)       // timing ablation only (wrong results): no refill of the ring
+        return;
+#endif
         if (!dma_wave()) return;
         const uint8_t* sbase = wstream + (cur_src + i * 1024);      // wave-uniform
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"

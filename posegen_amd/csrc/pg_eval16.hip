@@ -20,7 +20,10 @@
 namespace pgd {
 using namespace pgp::A;
 
-template <typename V, bool FC, bool FACT>
+// TAPS = the debug taps of pg_stage_eval compiled in: a separate instantiation, launched only when a dump
+// is asked for (the cold dump blocks otherwise cost the production kernel spilled registers, and every
+// scratch reload drains the weight DMA with its vmcnt(0))
+template <typename V, bool FC, bool FACT, bool TAPS>
 __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
             if (FACT) x_segment<V>(acc, st, C_L0, q_ab, cutv, tlv);
             else x_segment<V>(acc, st, C_L0, q_rows, cutv, tlv);
-            if (a.dbg && a.dbg_stage == 0 && valid) {
+            if (TAPS && a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
 #pragma unroll
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         // the host folds it into the view weights (pg_pack.cpp NetTensors::fold): one segment of
         // 1 + 4 out tiles on the last trunk activation instead of 9 + 4 ----
         float sigma;
-        dump_frags<V, HU>(a, 7, gp, valid, fb, h);
+        if (TAPS) dump_frags<V, HU>(a, 7, gp, valid, fb, h);
         V fg[HU / 2];
         {
             f32x16 acc[NTV];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             for (int o = 0; o < NTV; ++o) relu_pack<V>(acc[o], fg[2 * o], fg[2 * o + 1], true);
         }
         PG_STAMP(7);
-        dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
+        if (TAPS) dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
         // ---- rgb head ----
         f32x16 acc = load_bias(bias, BT_RGB, h);
         {
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC, bool FACT>
+template <typename V, bool FC, bool FACT, bool TAPS>
 static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16_kernel<V, FC, FACT>;
+    auto k = eval16_kernel<V, FC, FACT, TAPS>;
     constexpr int LDS = FACT ? LDS_TOTAL_F : LDS_TOTAL;
     static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
     int dev = -1;
@@ -236,8 +239,12 @@ static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream)
 template <typename V>
 static hipError_t dispatch_eval16(const pgd::EvalArgs& a, int framecode, int fact, int grid, hipStream_t s) {
     using namespace pgd;
-    if (fact) return framecode ? launch_eval16<V, true, true>(a, grid, s) : launch_eval16<V, false, true>(a, grid, s);
-    return framecode ? launch_eval16<V, true, false>(a, grid, s) : launch_eval16<V, false, false>(a, grid, s);
+    if (a.dbg && a.dbg_stage != 99) {
+        if (fact) return framecode ? launch_eval16<V, true, true, true>(a, grid, s) : launch_eval16<V, false, true, true>(a, grid, s);
+        return framecode ? launch_eval16<V, true, false, true>(a, grid, s) : launch_eval16<V, false, false, true>(a, grid, s);
+    }
+    if (fact) return framecode ? launch_eval16<V, true, true, false>(a, grid, s) : launch_eval16<V, false, true, false>(a, grid, s);
+    return framecode ? launch_eval16<V, true, false, false>(a, grid, s) : launch_eval16<V, false, false, false>(a, grid, s);
 }
 
 // fact = 1: factorised view layer (needs S >= pgl::FACT_MIN_S and the AF weight stream)

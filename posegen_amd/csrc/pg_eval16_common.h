@@ -101,6 +101,10 @@ __device__ __forceinline__ void lds_retire(a128& r, int younger) {
         case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
         case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
         case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r)); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(r)); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(r)); break;
+        case 7: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(r)); break;
+        case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r)); break;
         default: __builtin_unreachable();
     }
 }
@@ -116,6 +120,16 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
         return unit_of<V>(st, 0, q);
     }
     const int rem = min(T - 1 - L, UPC - 1 - q);      // later units of this segment in this chunk
+#if defined(PG_ABL_NOREAD)      // timing ablation only (wrong results): no ring reads, no waits
+    if (q == 0) { if (PG_SPREAD_DMA) st.enter_split(); else st.enter(L / UPC); }
+    if (PG_SPREAD_DMA) {
+        if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
+        if (L == T - 1)
+            for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
+    }
+    asm volatile("" : "+v"(p.r[L % NS]));
+    return __builtin_bit_cast(V, p.r[L % NS]);
+#endif
     if (q == 0) {
         if (PG_SPREAD_DMA) st.enter_split(); else st.enter(L / UPC);
         for (int k = 0; k < LA; ++k)

@@ -33,7 +33,10 @@ constexpr int NTHR_C = NWAVE_C * 64;
 constexpr int PTS_C = NWAVE_C * 32;
 using VC = f16x8;
 using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
-constexpr int NSC = 5;                        // register sets of the A pipe: reads issued 4 units = 2 pairs ahead
+#ifndef PG_NSC
+#define PG_NSC 4
+#endif
+constexpr int NSC = PG_NSC;                   // register sets of the A pipe: reads issued NSC-1 PAIRS of units ahead
 constexpr int LDS_TOTAL_C = LDS_RTAB + MAXR_C * SLOTC_FLOATS * 4;
 static_assert(LDS_TOTAL_C <= 160 * 1024, "LDS budget of one CU");
 
@@ -56,15 +59,24 @@ __device__ __forceinline__ void conv_a(float a, float b, float& ra, float& rb, u
 // step B: d = x - x1 (exact), t = S d + x1, x2 pair = f16(t).  v_fma_mix_f32 reads the fp16 halves of
 // `h` directly.  The trailing s_nop 1 provides the wait states a VALU write needs before an MFMA may
 // read the register (hipcc pads nothing for inline asm).
+template <bool NOP = true>
 __device__ __forceinline__ unsigned conv_b(float ra, float rb, unsigned h, float s) {
     unsigned x2;
     float da, db;
-    asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %1, %1, %6, %3 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %2, %2, %6, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1"
-        : "=&v"(x2), "=&v"(da), "=&v"(db) : "v"(h), "v"(ra), "v"(rb), "s"(s));
+    if (NOP)
+        asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %1, %1, %6, %3 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mix_f32 %2, %2, %6, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1"
+            : "=&v"(x2), "=&v"(da), "=&v"(db) : "v"(h), "v"(ra), "v"(rb), "s"(s));
+    else        // the fragment is consumed a whole unit row later: no wait states needed
+        asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %1, %1, %6, %3 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mix_f32 %2, %2, %6, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_cvt_pk_f16_f32 %0, %1, %2"
+            : "=&v"(x2), "=&v"(da), "=&v"(db) : "v"(h), "v"(ra), "v"(rb), "s"(s));
     return x2;
 }
 
@@ -75,15 +87,83 @@ __device__ __forceinline__ VC frag_v(const unsigned* p) {
     return __builtin_bit_cast(VC, v);
 }
 
+// ---- the A operand pair pipe -------------------------------------------------------------------
+// A wave issues one instruction per ~4 cycles, so with one wave per SIMD an MFMA slot (32 cycles) has
+// room for ~7 other instructions: every instruction per MFMA counts.  Versus the per-unit pipe of
+// pg_eval16_common.h (next_a) this one works on PAIRS of 1-KiB units (the two planes of one weight
+// tile), retires a pair with ONE counted wait, and does so between the two MFMAs of the PREVIOUS
+// pair, so that the registers the wait "writes" (as far as hipcc knows) are not read by the very
+// next instruction (which costs an s_nop per MFMA).  Refill pieces share their SGPR bases in
+// groups of four through the instruction's offset field (it applies to the global and the LDS
+// address alike): 2.75 instead of 6 instructions per piece.
+constexpr int PPC = CHUNK_BYTES / 2048;       // pairs per chunk
+template <int NS> struct PairPipe {
+    a128 r[NS][2];
+    const uint8_t* g;      // global base of this wave's current group of four refill pieces
+    uint32_t m;            // its LDS base (m0)
+};
+
+__device__ __forceinline__ void retire_pair(a128& r0, a128& r1, int younger) {
+    switch (younger) {   // constant after unrolling: LGKM operations younger than the pair
+#define PG_RP(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1)); break;
+        PG_RP(0) PG_RP(1) PG_RP(2) PG_RP(3) PG_RP(4) PG_RP(5) PG_RP(6) PG_RP(7) PG_RP(8)
+#undef PG_RP
+        default: __builtin_unreachable();
+    }
+}
+
+template <int NS, typename ST>
+__device__ __forceinline__ void piece_c(PairPipe<NS>& p, const ST& st, int i) {
+#if defined(PG_ABL_NODMA)       // timing ablation only (wrong results): no refill of the ring
+    return;
+#endif
+    if ((i & 3) == 0) {
+        p.g = st.wstream + (st.cur_src + i * 1024);
+        p.m = st.ring_lds + st.cur_dst + i * 1024;
+        asm volatile("" : "+s"(p.g), "+s"(p.m));
+    }
+    switch (i & 3) {
+#define PG_PC(K) case K: asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2 offset:" #K "*1024" \
+                                      :: "s"(p.m), "v"(st.lane16), "s"(p.g) : "memory"); break;
+        PG_PC(0) PG_PC(1) PG_PC(2) PG_PC(3)
+#undef PG_PC
+    }
+}
+
+// before the first MFMA of pair P (of a segment with TP pairs): chunk entry, and the pair must be there
+template <int TP, int NS, typename ST>
+__device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
+    constexpr int LA = NS - 1;
+    if (P % PPC != 0) return;
+    st.enter_split();
+    const int rem = min(TP - 1 - P, PPC - 1);            // later pairs of this segment in this chunk
+#pragma clang loop unroll(full)
+    for (int k = 0; k < LA; ++k)
+        if (k <= rem) { st.issue(p.r[(P + k) % NS][0], 2 * k); st.issue(p.r[(P + k) % NS][1], 2 * k + 1); }
+    retire_pair(p.r[P % NS][0], p.r[P % NS][1], 2 * min(LA - 1, rem));
+}
+// between the two MFMAs of pair P: read pair P+LA, one refill piece every other pair, retire pair P+1
+template <int TP, int NS, typename ST>
+__device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
+    constexpr int LA = NS - 1;
+    const int q = P % PPC;
+    const int rem = min(TP - 1 - P, PPC - 1 - q);
+    if (LA <= rem) { st.issue(p.r[(P + LA) % NS][0], 2 * (q + LA)); st.issue(p.r[(P + LA) % NS][1], 2 * (q + LA) + 1); }
+    if (q & 1) piece_c(p, st, q >> 1);
+    if (P == TP - 1)            // a segment ending inside the chunk flushes the rest of the refill
+        for (int i = (q + 1) >> 1; i < ST::PER; ++i) piece_c(p, st, i);
+    if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], 2 * min(LA - 1, rem - 1));
+}
+
 // One k-major segment: NU input units against NO out tiles, `src(u, e)` = value e of unit u (indices
 // are compile-time constants after unrolling).  While the 2 NO MFMAs of unit u issue, unit u+1 is
 // read, (ReLU'd,) and split: 8 half steps (A and B of 4 value pairs) spread over the NO out tiles.
 // T = units (of 1 KiB) of the segment in the weight stream: 2 per (input unit, out tile).
 template <int NO, int NU, bool RELU, typename ST, typename SRC>
 __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, float s129) {
-    constexpr int T = NU * NO * 2;
+    constexpr int TP = NU * NO;
     constexpr int PER = (8 + NO - 1) / NO;            // half steps per out tile
-    APipe<VC, NSC> p;
+    PairPipe<NSC> p;
     FragC cur, nxt;
     float ra = 0.f, rb = 0.f;
 #pragma unroll
@@ -95,22 +175,36 @@ __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, f
     for (int u = 0; u < NU; ++u) {
 #pragma clang loop unroll(full)
         for (int o = 0; o < NO; ++o) {
-            const int L = (u * NO + o) * 2;
-            const VC a1 = next_a<VC, T, true, NSC>(p, st, L);
-            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag_v(cur.x1), acc[o], 0, 0, 0);
-            const VC a2 = next_a<VC, T, true, NSC>(p, st, L + 1);
-            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, frag_v(cur.x2), acc[o], 0, 0, 0);
+            const int P = u * NO + o;
+            pair_begin<TP>(p, st, P);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(cur.x1), acc[o], 0, 0, 0);
+            pair_mid<TP>(p, st, P);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(cur.x2), acc[o], 0, 0, 0);
+            // second gap of the pair: one half step of the next unit's split
+#if defined(PG_ABL_NOCONV)      // timing ablation only (wrong results): the next unit's values are kept live but not split
             if (u + 1 < NU) {
+#pragma clang loop unroll(full)
+                for (int hs = o * PER; hs < (o + 1) * PER && hs < 8; ++hs)
+                    if ((hs & 1) == 0) asm volatile("" :: "v"(src(u + 1, hs)), "v"(src(u + 1, hs + 1)));
+            }
+            if (false) {
+#else
+            if (u + 1 < NU) {
+#endif
 #pragma clang loop unroll(full)
                 for (int hs = o * PER; hs < (o + 1) * PER && hs < 8; ++hs) {
                     const int j = hs >> 1;
                     if ((hs & 1) == 0) conv_a<RELU>(src(u + 1, 2 * j), src(u + 1, 2 * j + 1), ra, rb, nxt.x1[j]);
-                    else nxt.x2[j] = conv_b(ra, rb, nxt.x1[j], s129);
+                    else nxt.x2[j] = conv_b<(NO < 2)>(ra, rb, nxt.x1[j], s129);
                 }
             }
+#if !defined(PG_ABL_NOSCHEDBAR)
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#if !defined(PG_ABL_NOCONV)
         cur = nxt;
+#endif
     }
 }
 
@@ -135,15 +229,15 @@ __device__ __forceinline__ void joint_values_c(float qx, float qy, float qz, flo
 }
 
 // one input unit already in registers against NO out tiles (x segments: no look-ahead conversion here)
-template <int NO, int T, typename ST>
-__device__ __forceinline__ void mma_row_c(f32x16* acc, APipe<VC, NSC>& p, ST& st, int uu, const FragC& b) {
+template <int NO, int TP, typename ST>
+__device__ __forceinline__ void mma_row_c(f32x16* acc, PairPipe<NSC>& p, ST& st, int uu, const FragC& b) {
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-        const int L = (uu * NO + o) * 2;
-        const VC a1 = next_a<VC, T, true, NSC>(p, st, L);
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag_v(b.x1), acc[o], 0, 0, 0);
-        const VC a2 = next_a<VC, T, true, NSC>(p, st, L + 1);
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, frag_v(b.x2), acc[o], 0, 0, 0);
+        const int P = uu * NO + o;
+        pair_begin<TP>(p, st, P);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(b.x1), acc[o], 0, 0, 0);
+        pair_mid<TP>(p, st, P);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(b.x2), acc[o], 0, 0, 0);
     }
 }
 
@@ -163,8 +257,8 @@ __device__ __forceinline__ FragC frag_of(const float* x, float s129) {
 template <typename ST>
 __device__ __forceinline__ void x_segment_c(f32x16* acc, ST& st, const float* ab, float z, const float* cutb,
                                             float tl, float s129) {
-    APipe<VC, NSC> p;
-    constexpr int T = pgp::C::XU * NT * 2;
+    PairPipe<NSC> p;
+    constexpr int T = pgp::C::XU * NT;
     auto values = [&](int jj, float* x) {
         const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
         const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
@@ -252,7 +346,10 @@ __device__ __forceinline__ void ray_table_c(const EvalArgs& a, float* rt, int r0
     }
 }
 
-template <bool FC>
+// TAPS = the debug taps of pg_stage_eval (dbg_stage 0, 7, 9, 10) compiled in: a separate instantiation,
+// launched only when a dump is asked for -- the cold dump blocks (128 live values each) otherwise cost the
+// production kernel 34 spilled registers, and every scratch reload drains the weight DMA (vmcnt(0))
+template <bool FC, bool TAPS>
 __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
@@ -271,7 +368,14 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     asm volatile("" : "+s"(s129));              // one SGPR for the whole kernel, not a literal per use
     st.start();
 
+#if defined(PG_STAMPS)
+    unsigned long long stamps[14];
+#endif
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        PG_STAMP(0);
+#if defined(PG_STAMPS)
+        { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[10] = t_; }
+#endif
         const long long p0 = (long long)it * PTS_C;
         const long long plast = min(p0 + PTS_C - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
@@ -291,17 +395,19 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         const float* tab = opaque_ptr(slot + SLOTC_DTAB + h * DSEQ);
         const float zz = a.z[gpc];
 
+        PG_STAMP(1);
         f32x16 accA[NT], accB[NT];
         // ---- layer 0: K = 432 generated on the fly ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + o, h);
         x_segment_c(accA, st, ab, zz, cutv, tlv, s129);
-        if (a.dbg && a.dbg_stage == 0 && valid) {
+        if (TAPS && a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
             for (int o = 0; o < NT; ++o)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a.dbg[gp * W + 32 * o + rho(r, h)] = accA[o][r];
         }
+        PG_STAMP(2);
         // ---- layers 1..4 (ping-pong between the two accumulator sets) ----
         auto srcA = [&](int u, int e) { return accA[u >> 1][8 * (u & 1) + e]; };
         auto srcB = [&](int u, int e) { return accB[u >> 1][8 * (u & 1) + e]; };
@@ -317,11 +423,14 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 4 * NT + o, h);
         segment_c<NT, HU, true>(accA, st, srcB, s129);
+        PG_STAMP(3);
         // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
         segment_c<NT, HU, true>(accB, st, srcA, s129);
+        PG_STAMP(4);
         x_segment_c(accB, st, ab, zz, cutv, tlv, s129);
+        PG_STAMP(5);
         // ---- layers 6, 7 ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 6 * NT + o, h);
@@ -329,10 +438,11 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 7 * NT + o, h);
         segment_c<NT, HU, true>(accB, st, srcA, s129);
-        if (a.dbg && a.dbg_stage == 7 && valid) {
+        if (TAPS && a.dbg && a.dbg_stage == 7 && valid) {
 #pragma unroll
             for (int i = 0; i < HSEQ; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(accB[i >> 4][i & 15], 0.0f);
         }
+        PG_STAMP(6);
         // ---- sigma head and the view layer's trunk part in one segment of 1 + 4 out tiles: feature_linear
         // has no activation and is folded into the view weights on the host (NetTensors::fold) ----
         f32x16 av[NTV + 1];
@@ -341,6 +451,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         for (int o = 0; o < NTV; ++o) av[1 + o] = load_bias(bias, BT_VIEWF + o, h);
         segment_c<NTV + 1, HU, true>(av, st, srcB, s129);
         const float sigma = av[0][0];
+        PG_STAMP(7);
         // ---- view directions: per-ray sin/cos table in LDS times the per-point cutoff weight ----
         {
             float wd[JH];
@@ -351,7 +462,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
                 const float qx = fmaf(zz, hi.x, lo.x), qy = fmaf(zz, hi.y, lo.y), qz = fmaf(zz, hi.z, lo.z);
                 wd[jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
             }
-            if (a.dbg && a.dbg_stage == 10 && valid) {
+            if (TAPS && a.dbg && a.dbg_stage == 10 && valid) {
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) a.dbg[gp * W + JH * h + jj] = wd[jj];
             }
@@ -363,23 +474,45 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
             };
             segment_c<NTV, pgp::C::DU + (FC ? 1 : 0), false>(av + 1, st, srcD, s129);
         }
-        if (a.dbg && a.dbg_stage == 9 && valid) {
+        if (TAPS && a.dbg && a.dbg_stage == 9 && valid) {
 #pragma unroll
             for (int i = 0; i < VW / 2; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(av[1 + (i >> 4)][i & 15], 0.0f);
         }
+        PG_STAMP(8);
         // ---- rgb head ----
         f32x16 accr = load_bias(bias, BT_RGB, h);
         auto srcV = [&](int u, int e) { return av[1 + (u >> 1)][8 * (u & 1) + e]; };
         segment_c<1, HU / 2, true>(&accr, st, srcV, s129);
+#if defined(PG_STAMPS_RGB)
+        PG_STAMP(9);
+#endif
+#if defined(PG_ABL_NOSTORE)     // timing ablation only: results kept live, not stored
+        asm volatile("" :: "v"(accr[0]), "v"(accr[1]), "v"(accr[2]), "v"(sigma));
+#else
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
+#endif
+#if !defined(PG_STAMPS_RGB)
+        PG_STAMP(9);
+#endif
+#if defined(PG_STAMPS)
+        { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[11] = t_; }
+        if (a.dbg && a.dbg_stage == 99 && lane == 0 && it < 64) {
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 12] = stamps[10];
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 13] = stamps[11];
+            for (int k = 0; k < 10; ++k) reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + k] = stamps[k];
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 10] = st.t_vm;
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * 8 + wave) * 16 + 11] = st.t_bar;
+            st.t_vm = 0; st.t_bar = 0;
+        }
+#endif
     }
     st.drain();
 }
 
-template <bool FC>
+template <bool FC, bool TAPS>
 static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = evalc_kernel<FC>;
+    auto k = evalc_kernel<FC, TAPS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_C);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_C), LDS_TOTAL_C, stream, a);
@@ -391,7 +524,8 @@ static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) 
 // needs S >= pgl::COMP_MIN_S, rays (no explicit points) and the shape-C stream (pg_pack.cpp)
 extern "C" int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return (int)(framecode ? pgd::launch_evalc<true>(*a, grid, s) : pgd::launch_evalc<false>(*a, grid, s));
+    if (a->dbg && a->dbg_stage != 99) return (int)(framecode ? pgd::launch_evalc<true, true>(*a, grid, s) : pgd::launch_evalc<false, true>(*a, grid, s));
+    return (int)(framecode ? pgd::launch_evalc<true, false>(*a, grid, s) : pgd::launch_evalc<false, false>(*a, grid, s));
 }
 
 extern "C" int pg_evalc_points_per_pass(void) { return pgd::PTS_C; }
