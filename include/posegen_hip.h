@@ -98,10 +98,16 @@ typedef struct pg_handle pg_handle;
 
 int pg_abi_version(void);
 
-/* Replaces create_raycaster (core/raycasters.py:17-184): builds the renderer for one
- * HIP device.  n_devices must be 1 (one process per GPU; frames are partitioned
- * across ranks by the host). */
+/* Replaces create_raycaster (core/raycasters.py:17-184) and its nn.DataParallel wrapper
+ * (raycasters.py:157, re-pointed at run_gan.py:162-163): builds the renderer on n_devices HIP
+ * devices of THIS process (1..64; device_ids required for more than one; a device may be listed
+ * twice).  The weights are replicated once per device at load time.  Ray-level calls
+ * (pg_render_rays, pg_render_frame, pg_stage_*, pg_query_density, pg_pose_kinematics) run on
+ * device_ids[0]; pg_render_frames spreads frames over all of them.  Limits of the fused kernels:
+ * N_samples in [16, 256] (32 for the 16-bit and compensated kernels' fast paths, below that the
+ * k-major kernel runs), N_importance in {0, 2..64}, N_samples + N_importance <= 256. */
 int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_handle** out);
+int pg_device_count(const pg_handle* h);
 void pg_destroy(pg_handle* h);
 const char* pg_last_error(const pg_handle* h);   /* h may be NULL: last global error */
 
@@ -166,6 +172,28 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
                     const int* box, float near, float far, const float* skts, const float* cyl, float cam,
                     int n_samples, int n_importance, int flags, const float* bg, float base_bg,
                     float* rgb, float* disp, float* acc, uint8_t* rgb8);
+
+/* Frames on all devices of the handle, host in / host out: replaces the frame loop of render_path
+ * (run_nerf.py:27-147) together with nn.DataParallel's scatter / gather.
+ * One host thread and one stream per device; whole frames go to devices by longest-processing-
+ * time on the ray count of their boxes; with fewer frames than devices a frame's nanmean groups
+ * (`chunk` consecutive rays) are cut into contiguous runs, rendered on several devices, gathered on
+ * the frame's owner by device-to-device copies and composed there -- the result is bit-identical to
+ * one device either way.  No collective on the data path.
+ *   c2ws [F,3,4], intrinsics [F,4], boxes [F,4] (tl_x, tl_y, br_x, br_y), skts [F,24,4,4], cyls [F,5],
+ *   cams [F] or NULL: HOST; bg HOST [H*W,3] or NULL (one background for all frames)
+ *   rgbs [F,H,W,3] f32, disps [F,H,W], accs [F,H,W], rgb8 [F,H,W,3] u8: HOST outputs, any but one of
+ *   rgbs / rgb8 may be NULL.  Synchronous. */
+int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws, const float* intrinsics,
+                     const int* boxes, float near, float far, const float* skts, const float* cyls,
+                     const float* cams, int n_samples, int n_importance, int flags, const float* bg, float base_bg,
+                     float* rgbs, float* disps, float* accs, uint8_t* rgb8);
+
+/* Host-only: the work plan pg_render_frames uses (tests): tasks (frame, ray_begin,
+ * ray_end, worker, owner) for frames of n_rays[f] rays on n_workers devices with nanmean groups of
+ * `chunk` rays.  out_tasks [cap,5] may be NULL to query n_tasks. */
+int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk, int32_t* out_tasks, int cap,
+                   int* n_tasks);
 
 /* Batched pose kinematics on the device: replaces get_smpl_l2ws and
  * the kp / skts derivation of load_retarget (core/utils/skeleton_utils.py:379-463,

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <utility>
 #include <vector>
@@ -42,7 +44,7 @@ struct FrameGeom {
 };
 }
 extern "C" {
-int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream);
+int pg_launch_frame_rays(const pgk::FrameGeom* g, long long i0, long long n, float* rays, float* cams, void* stream);
 int pg_launch_pose_kinematics(const double* offs72, const int* parents24, const double* bones, long long n,
                               float* kps, float* skts, double* l2ws, void* stream);
 int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map, const float* acc_map,
@@ -54,7 +56,7 @@ namespace {
 
 using namespace pgl;
 
-char g_last_error[512] = "";
+thread_local char g_last_error[512] = "";      // pg_last_error(NULL): per host thread
 
 struct NetState {
     bool loaded = false;
@@ -87,6 +89,11 @@ struct pg_handle {
     size_t ws_bytes = 0;
     uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
     size_t fws_bytes = 0;
+    // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
+    // further device; every handle has a stream and a small pose buffer of its own for that path
+    std::vector<pg_handle*> peers;
+    hipStream_t own_stream = nullptr;
+    float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
@@ -111,6 +118,16 @@ int fail(pg_handle* h, int code, const char* fmt, ...) {
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess)                                                                \
             return fail(h, PG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// state setters are forwarded to the sub-handles of a multi-device handle (message of a failing one is kept)
+#define PG_FORWARD(h, call)                                                                  \
+    do {                                                                                     \
+        for (pg_handle* sub_ : (h)->peers) {                                                 \
+            pg_handle* hh = sub_;                                                            \
+            const int rc_ = (call);                                                          \
+            if (rc_) return fail(h, rc_, "device %d: %s", hh->device, hh->err);              \
+        }                                                                                    \
     } while (0)
 
 bool is_shape_a(int prec) { return prec == PG_PREC_BF16 || prec == PG_PREC_FP16; }
@@ -299,7 +316,8 @@ const char* pg_last_error(const pg_handle* h) { return h ? h->err : g_last_error
 int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_handle** out) {
     if (!cfg || !out) return fail(nullptr, PG_EINVAL, "pg_create: null argument");
     *out = nullptr;
-    if (n_devices != 1) return fail(nullptr, PG_EINVAL, "pg_create: n_devices must be 1 (one process per GPU), got %d", n_devices);
+    if (n_devices < 1 || n_devices > 64) return fail(nullptr, PG_EINVAL, "pg_create: n_devices must be 1..64, got %d", n_devices);
+    if (n_devices > 1 && !device_ids) return fail(nullptr, PG_EINVAL, "pg_create: device_ids required for n_devices > 1");
     if (cfg->n_joints != J || cfg->multires != LV || cfg->multires_views != LD || cfg->multires_bones != 0 ||
         cfg->net_depth != DEPTH || cfg->net_width != W || cfg->skip_layer != SKIP || cfg->view_width != VW ||
         (cfg->framecode_ch != 0 && cfg->framecode_ch != FC_CH))
@@ -331,14 +349,30 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
         delete h;
         return fail(nullptr, PG_ENOMEM, "pg_create: device allocation failed");
     }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->d_pose), (24 * 16 + 8) * sizeof(float)) != hipSuccess) {
+        pg_destroy(h);
+        return fail(nullptr, PG_ENOMEM, "pg_create: stream / pose buffer creation failed");
+    }
+    // further devices: one sub-handle each (the same device may be listed twice: two workers on one GPU)
+    for (int i = 1; i < n_devices; ++i) {
+        pg_handle* sub = nullptr;
+        const int rc = pg_create(cfg, 1, &device_ids[i], &sub);
+        if (rc) { pg_destroy(h); return rc; }
+        h->peers.push_back(sub);
+    }
     *out = h;
     return PG_OK;
 }
 
 void pg_destroy(pg_handle* h) {
     if (!h) return;
+    for (pg_handle* sub : h->peers) pg_destroy(sub);
+    h->peers.clear();
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->d_pose) (void)hipFree(h->d_pose);
     if (h->fws) (void)hipFree(h->fws);
     for (NetState& ns : h->net) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
@@ -392,7 +426,10 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
-    return ensure_stream(h, which, h->cfg.precision, use_fact(h->cfg.precision, FACT_MIN_S));
+    const int rc0 = ensure_stream(h, which, h->cfg.precision, use_fact(h->cfg.precision, FACT_MIN_S));
+    if (rc0) return rc0;
+    PG_FORWARD(h, pg_load_weights(hh, which, tensors, shapes, n_tensors));
+    return PG_OK;
 }
 
 int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau) {
@@ -403,6 +440,7 @@ int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau
     h->emb_set[which] = true;
     PG_HIP(h, hipSetDevice(h->device));
     PG_HIP(h, hipMemcpy(h->d_cut, h->cut, sizeof h->cut, hipMemcpyHostToDevice));
+    PG_FORWARD(h, pg_set_embedder(hh, which, cutoff_dist, tau));
     return PG_OK;
 }
 
@@ -424,6 +462,7 @@ int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) 
     if (ns.d_codes) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_codes)); ns.d_codes = nullptr; }
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_codes), ns.codes_host.size() * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_codes, ns.codes_host.data(), ns.codes_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    PG_FORWARD(h, pg_set_framecodes(hh, which, codes, n_codes));
     return PG_OK;
 }
 
@@ -435,6 +474,7 @@ int pg_set_precision(pg_handle* h, int precision) {
     h->cfg.precision = precision;
     for (int w = 0; w < 2; ++w)
         if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision, use_fact(precision, FACT_MIN_S)); if (rc) return rc; }
+    PG_FORWARD(h, pg_set_precision(hh, precision));
     return PG_OK;
 }
 
@@ -442,6 +482,7 @@ int pg_set_chunk(pg_handle* h, int chunk) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_set_chunk: null handle");
     if (chunk <= 0) return fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
     h->cfg.chunk = chunk;
+    PG_FORWARD(h, pg_set_chunk(hh, chunk));
     return PG_OK;
 }
 
@@ -675,29 +716,35 @@ int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double
     return PG_OK;
 }
 
-int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
-                    const int* box, float near, float far, const float* skts, const float* cyl, float cam,
-                    int n_samples, int n_importance, int flags, const float* bg, float base_bg,
-                    float* rgb, float* disp, float* acc, uint8_t* rgb8) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (H <= 0 || W <= 0 || !c2w || !intrinsics || !box || !skts || !cyl || !rgb)
-        return fail(h, PG_EINVAL, "pg_render_frame: null/non-positive argument");
-    pgk::FrameGeom g{};
-    g.H = H; g.W = W;
-    g.tlx = box[0] < 0 ? 0 : box[0]; g.tly = box[1] < 0 ? 0 : box[1];
+// ---- frame front / back end: helpers shared by pg_render_frame (one device) and pg_render_frames ----
+namespace {
+
+struct FrameMaps { float *rgb_map, *disp_map, *acc_map; };      // [n_box,3], [n_box], [n_box]: the whole box
+
+int frame_geom(pg_handle* h, int H, int W, const float* c2w, const float* intrinsics, const int* box, float near,
+               float far, float cam, pgk::FrameGeom* g) {
+    if (H <= 0 || W <= 0 || !c2w || !intrinsics || !box) return fail(h, PG_EINVAL, "frame: null/non-positive argument");
+    g->H = H; g->W = W;
+    g->tlx = box[0] < 0 ? 0 : box[0]; g->tly = box[1] < 0 ? 0 : box[1];
     const int brx = box[2] > W ? W : box[2], bry = box[3] > H ? H : box[3];
-    g.bw = brx > g.tlx ? brx - g.tlx : 0; g.bh = bry > g.tly ? bry - g.tly : 0;
-    g.fx = intrinsics[0]; g.fy = intrinsics[1]; g.cx = intrinsics[2]; g.cy = intrinsics[3];
+    g->bw = brx > g->tlx ? brx - g->tlx : 0; g->bh = bry > g->tly ? bry - g->tly : 0;
+    g->fx = intrinsics[0]; g->fy = intrinsics[1]; g->cx = intrinsics[2]; g->cy = intrinsics[3];
     for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) g.R[3 * r + c] = c2w[4 * r + c];
-        g.t[r] = c2w[4 * r + 3];
+        for (int c = 0; c < 3; ++c) g->R[3 * r + c] = c2w[4 * r + c];
+        g->t[r] = c2w[4 * r + 3];
     }
-    g.near = near; g.far = far; g.cam = cam;
-    const int64_t n = (int64_t)g.bw * g.bh;
-    PG_HIP(h, hipSetDevice(h->device));
+    g->near = near; g->far = far; g->cam = cam;
+    return PG_OK;
+}
+
+// Frame workspace of `h` for a box of n rays of which a range of at most n_range is rendered here:
+// ray_batch rows and cams of the range, the maps of the WHOLE box (a range writes at its offset, so
+// that a partner device's share can be copied in at the same offset), coarse-pass scratch of the range.
+int frame_ws(pg_handle* h, int64_t n, int64_t n_range, float** rays, float** cams, FrameMaps* maps, pg_outputs* scratch) {
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
-    const size_t b_rays = al((size_t)n * 44), b_cam = al((size_t)n * 4), b_rgb = al((size_t)n * 12), b_1 = al((size_t)n * 4);
-    const size_t need = b_rays + b_cam + 2 * b_rgb + 4 * b_1;
+    const size_t b_rays = al((size_t)n_range * 44), b_cam = al((size_t)n_range * 4);
+    const size_t b_rgb = al((size_t)n * 12), b_1 = al((size_t)n * 4), r_rgb = al((size_t)n_range * 12), r_1 = al((size_t)n_range * 4);
+    const size_t need = b_rays + b_cam + b_rgb + 2 * b_1 + r_rgb + 2 * r_1;
     if (need > h->fws_bytes) {
         if (h->fws) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->fws)); h->fws = nullptr; h->fws_bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->fws), need + need / 8);
@@ -705,25 +752,274 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
         h->fws_bytes = need + need / 8;
     }
     uint8_t* p = h->fws;
-    float* rays = reinterpret_cast<float*>(p); p += b_rays;
-    float* cams = reinterpret_cast<float*>(p); p += b_cam;
+    *rays = reinterpret_cast<float*>(p); p += b_rays;
+    *cams = reinterpret_cast<float*>(p); p += b_cam;
+    maps->rgb_map = reinterpret_cast<float*>(p); p += b_rgb;
+    maps->disp_map = reinterpret_cast<float*>(p); p += b_1;
+    maps->acc_map = reinterpret_cast<float*>(p); p += b_1;
+    scratch->rgb0 = reinterpret_cast<float*>(p); p += r_rgb;
+    scratch->disp0 = reinterpret_cast<float*>(p); p += r_1;
+    scratch->acc0 = reinterpret_cast<float*>(p);
+    return PG_OK;
+}
+
+// rays [r0, r1) of the box (row-major ray list of kp_to_valid_rays) -> maps[r0 .. r1).  r0 must be a multiple of
+// the nanmean group size (`chunk`) unless it is 0, so that the groups are those of the whole frame.
+int frame_render_range(pg_handle* h, void* stream, const pgk::FrameGeom& g, int64_t r0, int64_t r1, const float* skts,
+                       const float* cyl, int n_samples, int n_importance, int flags, FrameMaps* maps) {
+    const int64_t n = (int64_t)g.bw * g.bh;
+    if (r0 < 0 || r1 > n || r0 > r1) return fail(h, PG_EINVAL, "frame range [%lld, %lld) outside the box of %lld rays", (long long)r0, (long long)r1, (long long)n);
+    if (r0 % h->cfg.chunk != 0) return fail(h, PG_EINVAL, "frame range must start on a nanmean group boundary (chunk %d)", h->cfg.chunk);
+    PG_HIP(h, hipSetDevice(h->device));
+    float *rays, *cams;
     pg_outputs out{};
-    out.rgb_map = reinterpret_cast<float*>(p); p += b_rgb;
-    out.rgb0 = reinterpret_cast<float*>(p); p += b_rgb;
-    out.disp_map = reinterpret_cast<float*>(p); p += b_1;
-    out.acc_map = reinterpret_cast<float*>(p); p += b_1;
-    out.disp0 = reinterpret_cast<float*>(p); p += b_1;
-    out.acc0 = reinterpret_cast<float*>(p);
+    int rc = frame_ws(h, n, r1 - r0, &rays, &cams, maps, &out);
+    if (rc) return rc;
+    if (r1 == r0) return PG_OK;
+    out.rgb_map = maps->rgb_map + r0 * 3; out.disp_map = maps->disp_map + r0; out.acc_map = maps->acc_map + r0;
     const bool fc = h->cfg.framecode_ch > 0;
-    if (n > 0) {
-        int e = pg_launch_frame_rays(&g, rays, fc ? cams : nullptr, stream);
-        if (e) return fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-        int rc = pg_render_rays(h, stream, n, rays, skts, 0, cyl, 0, fc ? cams : nullptr, n_samples, n_importance, flags, &out);
-        if (rc) return rc;
-    }
-    int e = pg_launch_frame_compose(&g, out.rgb_map, out.disp_map, out.acc_map, bg, base_bg, rgb, disp, acc, rgb8, stream);
+    int e = pg_launch_frame_rays(&g, r0, r1 - r0, rays, fc ? cams : nullptr, stream);
+    if (e) return fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return pg_render_rays(h, stream, r1 - r0, rays, skts, 0, cyl, 0, fc ? cams : nullptr, n_samples, n_importance, flags, &out);
+}
+
+int frame_compose(pg_handle* h, void* stream, const pgk::FrameGeom& g, const FrameMaps& maps, const float* bg, float base_bg,
+                  float* rgb, float* disp, float* acc, uint8_t* rgb8) {
+    int e = pg_launch_frame_compose(&g, maps.rgb_map, maps.disp_map, maps.acc_map, bg, base_bg, rgb, disp, acc, rgb8, stream);
     if (e) return fail(h, PG_EHIP, "frame compose kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
+}
+
+}  // namespace
+
+int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
+                    const int* box, float near, float far, const float* skts, const float* cyl, float cam,
+                    int n_samples, int n_importance, int flags, const float* bg, float base_bg,
+                    float* rgb, float* disp, float* acc, uint8_t* rgb8) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (!skts || !cyl || !rgb) return fail(h, PG_EINVAL, "pg_render_frame: null argument");
+    pgk::FrameGeom g{};
+    int rc = frame_geom(h, H, W, c2w, intrinsics, box, near, far, cam, &g);
+    if (rc) return rc;
+    FrameMaps maps{};
+    rc = frame_render_range(h, stream, g, 0, (int64_t)g.bw * g.bh, skts, cyl, n_samples, n_importance, flags, &maps);
+    if (rc) return rc;
+    return frame_compose(h, stream, g, maps, bg, base_bg, rgb, disp, acc, rgb8);
+}
+
+int pg_device_count(const pg_handle* h) { return h ? 1 + (int)h->peers.size() : 0; }
+
+// ---- in-process multi-device frame rendering -------------------------------------------------------
+namespace {
+
+struct FrameTask { int frame; int64_t r0, r1; int worker; int owner; };
+
+// Whole frames to workers by longest-processing-time (ray count of the box); with fewer frames than
+// workers, a frame's nanmean groups (`chunk` consecutive rays) are cut into contiguous runs over
+// several workers, so that every group is rendered exactly as on one device.
+void plan_frames(const std::vector<int64_t>& n_rays, int G, int chunk, std::vector<FrameTask>* tasks) {
+    const int F = (int)n_rays.size();
+    std::vector<int> order(F);
+    for (int f = 0; f < F; ++f) order[f] = f;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_rays[a] > n_rays[b]; });
+    tasks->clear();
+    if (F >= G) {
+        std::vector<int64_t> load(G, 0);
+        for (int f : order) {
+            int w = 0;
+            for (int k = 1; k < G; ++k) if (load[k] < load[w]) w = k;
+            load[w] += n_rays[f];
+            tasks->push_back({f, 0, n_rays[f], w, w});
+        }
+        return;
+    }
+    // F < G: workers per frame proportional to its size (largest remainder), at least one each
+    int64_t total = 0;
+    for (int64_t n : n_rays) total += n > 0 ? n : 1;
+    std::vector<int> share(F, 1);
+    int left = G - F;
+    std::vector<double> want(F);
+    for (int f = 0; f < F; ++f) want[f] = (double)(n_rays[f] > 0 ? n_rays[f] : 1) / (double)total * G;
+    while (left > 0) {
+        int best = 0;
+        for (int f = 1; f < F; ++f) if (want[f] - share[f] > want[best] - share[best]) best = f;
+        ++share[best];
+        --left;
+    }
+    int w = 0;
+    for (int f = 0; f < F; ++f) {
+        const int64_t groups = (n_rays[f] + chunk - 1) / chunk;
+        const int parts = (int)std::min<int64_t>(share[f], groups > 0 ? groups : 1);
+        const int owner = w;
+        for (int p = 0; p < parts; ++p) {
+            const int64_t g0 = groups * p / parts, g1 = groups * (p + 1) / parts;
+            tasks->push_back({f, std::min(g0 * chunk, n_rays[f]), std::min(g1 * chunk, n_rays[f]), w + p, owner});
+        }
+        w += share[f];          // workers beyond `parts` of a tiny frame stay idle
+    }
+}
+
+}  // namespace
+
+int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk, int32_t* out_tasks /*[cap,5]*/, int cap, int* n_tasks) {
+    if (n_frames < 0 || !n_rays || n_workers < 1 || chunk < 1 || !n_tasks) return fail(nullptr, PG_EINVAL, "pg_plan_frames: bad argument");
+    std::vector<FrameTask> t;
+    plan_frames(std::vector<int64_t>(n_rays, n_rays + n_frames), n_workers, chunk, &t);
+    *n_tasks = (int)t.size();
+    if (out_tasks) {
+        if ((int)t.size() > cap) return fail(nullptr, PG_EINVAL, "pg_plan_frames: %zu tasks exceed the capacity %d", t.size(), cap);
+        for (size_t i = 0; i < t.size(); ++i) {
+            out_tasks[5 * i] = t[i].frame; out_tasks[5 * i + 1] = (int32_t)t[i].r0; out_tasks[5 * i + 2] = (int32_t)t[i].r1;
+            out_tasks[5 * i + 3] = t[i].worker; out_tasks[5 * i + 4] = t[i].owner;
+        }
+    }
+    return PG_OK;
+}
+
+int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws, const float* intrinsics, const int* boxes,
+                     float near, float far, const float* skts, const float* cyls, const float* cams, int n_samples,
+                     int n_importance, int flags, const float* bg, float base_bg, float* rgbs, float* disps, float* accs,
+                     uint8_t* rgb8) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (n_frames < 0 || H <= 0 || W <= 0 || !c2ws || !intrinsics || !boxes || !skts || !cyls || (!rgbs && !rgb8))
+        return fail(h, PG_EINVAL, "pg_render_frames: null/negative argument");
+    if (n_frames == 0) return PG_OK;
+    std::vector<pg_handle*> wk;
+    wk.push_back(h);
+    for (pg_handle* s : h->peers) wk.push_back(s);
+    const int G = (int)wk.size();
+    const size_t hw = (size_t)H * W;
+    std::vector<pgk::FrameGeom> geo(n_frames);
+    std::vector<int64_t> nr(n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        const int rc = frame_geom(h, H, W, c2ws + 12 * f, intrinsics + 4 * f, boxes + 4 * f, near, far, cams ? cams[f] : -1.0f, &geo[f]);
+        if (rc) return rc;
+        nr[f] = (int64_t)geo[f].bw * geo[f].bh;
+    }
+    std::vector<FrameTask> tasks;
+    plan_frames(nr, G, h->cfg.chunk, &tasks);
+    // the background (shared by all frames) once per worker that composes
+    struct Worker { pg_handle* h; int rc = PG_OK; float* d_bg = nullptr; std::vector<float*> bufs; hipEvent_t done = nullptr; };
+    std::vector<Worker> ws(G);
+    for (int k = 0; k < G; ++k) ws[k].h = wk[k];
+    std::vector<FrameMaps> maps_of(tasks.size());
+
+    // phase A: every worker renders its ranges; whole frames are composed and copied out at once
+    auto phase_a = [&](int k) {
+        Worker& w = ws[k];
+        pg_handle* hh = w.h;
+        auto check = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(hh, PG_EHIP, "%s failed on device %d: %s", what, hh->device, hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        if (!check(hipSetDevice(hh->device), "hipSetDevice")) return;
+        hipStream_t st = hh->own_stream;
+        float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
+        uint8_t* d_rgb8 = nullptr;
+        for (size_t t = 0; t < tasks.size() && w.rc == PG_OK; ++t) {
+            const FrameTask& tk = tasks[t];
+            if (tk.worker != k) continue;
+            const int f = tk.frame;
+            // pose of the frame (skts may hold one pose for all frames: n_poses is not passed, F poses are)
+            if (!check(hipMemcpyAsync(hh->d_pose, skts + (size_t)f * 384, 384 * sizeof(float), hipMemcpyHostToDevice, st), "pose upload")) return;
+            if (!check(hipMemcpyAsync(hh->d_pose + 384, cyls + (size_t)f * 5, 5 * sizeof(float), hipMemcpyHostToDevice, st), "cylinder upload")) return;
+            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;      // the host rows may be pageable
+            w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t]);
+            if (w.rc) return;
+            const bool whole = tk.r0 == 0 && tk.r1 == nr[f];
+            if (!whole) {
+                // the partner (or the owner itself) waits for this range before it gathers: one range per
+                // worker when frames are split, so a stream synchronisation at the end of phase A is enough
+                continue;
+            }
+            if (!d_rgb) {
+                if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
+                    !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
+                    !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
+                    (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return;
+                w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
+                if (bg) {
+                    if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
+                        !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return;
+                }
+            }
+            w.rc = frame_compose(hh, st, geo[f], maps_of[t], w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
+            if (w.rc) return;
+            if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;      // the frame buffers are reused
+        }
+        check(hipStreamSynchronize(st), "hipStreamSynchronize");
+    };
+    // phase B: the owner of a split frame gathers its partners' ranges (device to device), composes, copies out
+    auto phase_b = [&](int k) {
+        Worker& w = ws[k];
+        pg_handle* hh = w.h;
+        auto check = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(hh, PG_EHIP, "%s failed on device %d: %s", what, hh->device, hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+        if (!check(hipSetDevice(hh->device), "hipSetDevice")) return;
+        hipStream_t st = hh->own_stream;
+        for (size_t t = 0; t < tasks.size() && w.rc == PG_OK; ++t) {
+            const FrameTask& own = tasks[t];
+            if (own.owner != k || own.worker != k || (own.r0 == 0 && own.r1 == nr[own.frame])) continue;
+            const int f = own.frame;
+            for (size_t u = 0; u < tasks.size(); ++u) {
+                const FrameTask& pt = tasks[u];
+                if (pt.frame != f || u == t || pt.r1 == pt.r0) continue;
+                const int src_dev = wk[pt.worker]->device;
+                const size_t n = (size_t)(pt.r1 - pt.r0);
+                if (!check(hipMemcpyPeerAsync(maps_of[t].rgb_map + pt.r0 * 3, hh->device, maps_of[u].rgb_map + pt.r0 * 3, src_dev, n * 12, st), "peer copy") ||
+                    !check(hipMemcpyPeerAsync(maps_of[t].disp_map + pt.r0, hh->device, maps_of[u].disp_map + pt.r0, src_dev, n * 4, st), "peer copy") ||
+                    !check(hipMemcpyPeerAsync(maps_of[t].acc_map + pt.r0, hh->device, maps_of[u].acc_map + pt.r0, src_dev, n * 4, st), "peer copy")) return;
+            }
+            float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
+            uint8_t* d_rgb8 = nullptr;
+            if (w.bufs.empty()) {
+                if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
+                    !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
+                    !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
+                    (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return;
+                w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
+                if (bg) {
+                    if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
+                        !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return;
+                }
+            }
+            d_rgb = w.bufs[0]; d_disp = w.bufs[1]; d_acc = w.bufs[2]; d_rgb8 = reinterpret_cast<uint8_t*>(w.bufs[3]);
+            w.rc = frame_compose(hh, st, geo[f], maps_of[t], w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
+            if (w.rc) return;
+            if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return;
+            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;
+        }
+    };
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (int k = 1; k < G; ++k) th.emplace_back(fn, k);
+        fn(0);
+        for (auto& t : th) t.join();
+    };
+    run(phase_a);
+    bool split = false;
+    for (const FrameTask& tk : tasks) split = split || !(tk.r0 == 0 && tk.r1 == nr[tk.frame]);
+    bool ok = true;
+    for (const Worker& w : ws) ok = ok && w.rc == PG_OK;
+    if (ok && split) run(phase_b);
+    int rc = PG_OK;
+    for (Worker& w : ws) {
+        (void)hipSetDevice(w.h->device);
+        for (float* b : w.bufs) if (b) (void)hipFree(b);
+        if (w.d_bg) (void)hipFree(w.d_bg);
+        if (w.rc && rc == PG_OK) rc = (w.h == h) ? w.rc : fail(h, w.rc, "device %d: %s", w.h->device, w.h->err);
+    }
+    (void)hipSetDevice(h->device);
+    return rc;
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "pg_program.h"
 
 namespace pgd {
@@ -34,6 +36,20 @@ struct EvalArgs {
     float tau_v, tau_d;
     int dbg_stage;            // which activation `dbg` receives (see pg_stage_eval)
 };
+
+// The opt-in to > 64 KiB of dynamic LDS is per (kernel, device): set once per device, from any host
+// thread (pg_render_frames drives one thread per device).
+inline hipError_t ensure_lds_attr(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,

@@ -221,15 +221,9 @@ template <typename V, bool FC, bool FACT, bool TAPS>
 static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval16_kernel<V, FC, FACT, TAPS>;
     constexpr int LDS = FACT ? LDS_TOTAL_F : LDS_TOTAL;
-    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev != attr_dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS, attr_done);
+    if (ae != hipSuccess) return ae;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS, stream, a);
     return hipGetLastError();
 }

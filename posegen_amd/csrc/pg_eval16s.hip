@@ -321,15 +321,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16s_kernel(const EvalArgs a) {
 template <typename V, bool FC>
 static hipError_t launch_eval16s(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval16s_kernel<V, FC>;
-    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev != attr_dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_F);
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL_F, attr_done);
+    if (ae != hipSuccess) return ae;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS_TOTAL_F, stream, a);
     return hipGetLastError();
 }

@@ -299,15 +299,9 @@ __global__ __launch_bounds__(NTHR_W, 1) void eval16w_kernel(const EvalArgs a) {
 template <typename V, bool FC>
 static hipError_t launch_eval16w(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval16w_kernel<V, FC>;
-    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev != attr_dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_F);
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL_F, attr_done);
+    if (ae != hipSuccess) return ae;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_W), LDS_TOTAL_F, stream, a);
     return hipGetLastError();
 }

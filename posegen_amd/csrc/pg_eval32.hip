@@ -332,15 +332,9 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
 template <typename P, bool FC>
 static hipError_t launch_eval32(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = eval32_kernel<P, FC>;
-    static int attr_dev = -1;       // the opt-in to > 64 KiB of LDS is per device
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
-    if (dev != attr_dev) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        attr_dev = dev;
-    }
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL, attr_done);
+    if (ae != hipSuccess) return ae;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_B), LDS_TOTAL, stream, a);
     return hipGetLastError();
 }

@@ -513,7 +513,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 template <bool FC, bool TAPS>
 static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) {
     auto k = evalc_kernel<FC, TAPS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_C);
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL_C, attr_done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_C), LDS_TOTAL_C, stream, a);
     return hipGetLastError();

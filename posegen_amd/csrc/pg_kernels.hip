@@ -307,10 +307,11 @@ struct FrameGeom {
 // ray_batch rows of the box's pixels (get_rays + the bbox gather of kp_to_valid_rays,
 // core/utils/ray_utils.py:6-28, 83-136, and the packing of trainer.py:118-137), in the
 // reference's row-major pixel order.  Plain fp32 ops in the reference's order, no FMA.
-__global__ __launch_bounds__(256) void frame_rays_kernel(const FrameGeom g, float* __restrict__ rays,
-                                                        float* __restrict__ cams) {
-    const long long n = (long long)g.bw * g.bh;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+// rays i0 .. i0+n of the box's row-major ray list go to rows 0 .. n of `rays` (a range: one device's share of a frame)
+__global__ __launch_bounds__(256) void frame_rays_kernel(const FrameGeom g, long long i0, long long n,
+                                                        float* __restrict__ rays, float* __restrict__ cams) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + k;
         const int r = g.tly + (int)(i / g.bw), c = g.tlx + (int)(i % g.bw);
         const float dx = __fdiv_rn(__fsub_rn((float)c, g.cx), g.fx);
         const float dy = -__fdiv_rn(__fsub_rn((float)r, g.cy), g.fy);
@@ -320,12 +321,12 @@ __global__ __launch_bounds__(256) void frame_rays_kernel(const FrameGeom g, floa
         for (int k = 0; k < 3; ++k)
             d[k] = __fadd_rn(__fadd_rn(__fmul_rn(dx, g.R[3 * k]), __fmul_rn(dy, g.R[3 * k + 1])), __fmul_rn(dz, g.R[3 * k + 2]));
         const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        float* o = rays + i * 11;
+        float* o = rays + k * 11;
         o[0] = g.t[0]; o[1] = g.t[1]; o[2] = g.t[2];
         o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
         o[6] = g.near; o[7] = g.far;
         o[8] = d[0] * inv; o[9] = d[1] * inv; o[10] = d[2] * inv;      // carried, unused (SURVEY a-5)
-        if (cams) cams[i] = g.cam;
+        if (cams) cams[k] = g.cam;
     }
 }
 
@@ -431,11 +432,10 @@ extern "C" int pg_launch_pose_kinematics(const double* offs72, const int* parent
     return (int)hipGetLastError();
 }
 
-extern "C" int pg_launch_frame_rays(const pgk::FrameGeom* g, float* rays, float* cams, void* stream) {
-    const long long n = (long long)g->bw * g->bh;
+extern "C" int pg_launch_frame_rays(const pgk::FrameGeom* g, long long i0, long long n, float* rays, float* cams, void* stream) {
     if (n <= 0) return 0;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pgk::frame_rays_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *g, rays, cams);
+    hipLaunchKernelGGL(pgk::frame_rays_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *g, i0, n, rays, cams);
     return (int)hipGetLastError();
 }
 

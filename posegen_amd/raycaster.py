@@ -42,10 +42,16 @@ def _ptr(t: Optional[torch.Tensor]):
 class HipRenderer:
     """Owns a pg_handle on one HIP device."""
 
-    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16, devices=None):
+        """`devices`: HIP device indices for in-process multi-GPU frame rendering (render_frames /
+        render_path); the first one is `device`, where every ray-level call runs.  An index may
+        repeat (two workers on one GPU)."""
         if isinstance(precision, str):
             precision = PREC_BY_NAME[precision]
         self.cfg = cfg
+        if devices is not None:
+            devices = [int(torch.device(d).index) if not isinstance(d, int) else int(d) for d in devices]
+            device = f"cuda:{devices[0]}"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _ffi.HipLibraryError("HipRenderer needs a HIP device (torch device 'cuda:N'); "
@@ -59,9 +65,11 @@ class HipRenderer:
                            precision=self.precision, cutoff_dist=cfg.cutoff_dist,
                            density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps, reserved0=0.0)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        ids = (C.c_int * 1)(idx)
+        dev_ids = [idx] if devices is None else devices
+        ids = (C.c_int * len(dev_ids))(*dev_ids)
+        self.devices = list(dev_ids)
         h = C.c_void_p()
-        rc = self.lib.pg_create(C.byref(pc), 1, ids, C.byref(h))
+        rc = self.lib.pg_create(C.byref(pc), len(dev_ids), ids, C.byref(h))
         _ffi.check(self.lib, None, rc)
         self.handle = h
         self._state: Dict[str, dict] = {}
@@ -241,6 +249,49 @@ class HipRenderer:
             _ptr(rgb8)))
         return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
 
+    @property
+    def n_devices(self) -> int:
+        return len(self.devices)
+
+    def render_frames(self, H: int, W: int, focals, c2ws, boxes, skts, cyls, centers=None, cams=None,
+                      near: float = 0., far: float = 1., n_samples: Optional[int] = None,
+                      n_importance: Optional[int] = None, lindisp: bool = False, bg=None, base_bg: float = 0.,
+                      want_uint8: bool = False):
+        """Frames on ALL devices of the handle (pg_render_frames), host in / host out: numpy arrays
+        rgbs [F,H,W,3], disps [F,H,W,1], accs [F,H,W,1] (+ rgb8 uint8 [F,H,W,3]).  `boxes` = list of
+        ((tl_x, tl_y), (br_x, br_y)); skts [F,24,4,4], cyls [F,5] (one pose per frame)."""
+        cfg = self.cfg
+        S = cfg.n_samples if n_samples is None else int(n_samples)
+        N = cfg.n_importance if n_importance is None else int(n_importance)
+        F = len(boxes)
+        c2w_h = np.ascontiguousarray(np.stack([np.asarray(torch.as_tensor(c).detach().cpu(), dtype=np.float32)[:3, :4]
+                                               for c in c2ws]))
+        intr = np.zeros((F, 4), dtype=np.float32)
+        for i in range(F):
+            f = np.asarray(torch.as_tensor(focals[i] if np.ndim(focals) > 0 else focals).detach().cpu(), dtype=np.float64).reshape(-1)
+            intr[i, 0], intr[i, 1] = (f[0], f[0]) if f.size < 2 else (f[0], f[1])
+            intr[i, 2], intr[i, 3] = (W * 0.5, H * 0.5) if centers is None else (float(centers[i][0]), float(centers[i][1]))
+        bx = np.ascontiguousarray(np.array([[b[0][0], b[0][1], b[1][0], b[1][1]] for b in boxes], dtype=np.int32))
+        sk = _np32(skts).reshape(-1, 24, 4, 4)
+        cy = _np32(cyls).reshape(-1, 5)
+        if sk.shape[0] == 1 and F > 1:
+            sk = np.ascontiguousarray(np.repeat(sk, F, 0))
+        if cy.shape[0] == 1 and F > 1:
+            cy = np.ascontiguousarray(np.repeat(cy, F, 0))
+        if sk.shape[0] != F or cy.shape[0] != F:
+            raise ValueError(f"need one pose per frame: {sk.shape[0]} skts / {cy.shape[0]} cyls for {F} frames")
+        cm = None if cams is None else _np32(cams).reshape(-1)
+        bgh = None if bg is None else _np32(bg).reshape(H * W, 3)
+        rgbs = np.empty((F, H, W, 3), dtype=np.float32)
+        disps = np.empty((F, H, W, 1), dtype=np.float32)
+        accs = np.empty((F, H, W, 1), dtype=np.float32)
+        rgb8 = np.empty((F, H, W, 3), dtype=np.uint8) if want_uint8 else None
+        hp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        self._check(self.lib.pg_render_frames(
+            self.handle, F, int(H), int(W), hp(c2w_h), hp(intr), hp(bx), float(near), float(far), hp(sk), hp(cy), hp(cm),
+            S, N, _ffi.PG_FLAG_LINDISP if lindisp else 0, hp(bgh), float(base_bg), hp(rgbs), hp(disps), hp(accs), hp(rgb8)))
+        return (rgbs, disps, accs, rgb8) if want_uint8 else (rgbs, disps, accs)
+
     def query_density(self, pts: torch.Tensor, skts: torch.Tensor, which: Optional[int] = None) -> torch.Tensor:
         """Raw density (alpha_linear output, no activation) of net `which` (default: the fine net if
         loaded, like the reference) at explicit points [...,3] for one pose: render_pts_density
@@ -335,15 +386,18 @@ class HipRayCaster:
     (core/raycasters.py:156-178) plus the per-ray pose tensors.
     """
 
-    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+    def __init__(self, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16, devices=None):
+        """`devices=[0, 1, ...]`: all GPUs of this process behind one caster, the replacement of
+        `nn.DataParallel(RayCaster)` (core/raycasters.py:157): `render_path` then spreads the frames
+        (or, with fewer frames than GPUs, the frames' ray chunks) over them inside one call."""
         self.cfg = cfg
-        self.renderer = HipRenderer(cfg, device, precision)
+        self.renderer = HipRenderer(cfg, device, precision, devices=devices)
         self.training = False
 
     # ---- construction helpers -------------------------------------------------------
     @classmethod
-    def from_weights(cls, cfg, w_coarse, w_fine, tau_v, tau_d, device="cuda:0", precision=PREC_BF16):
-        rc = cls(cfg, device, precision)
+    def from_weights(cls, cfg, w_coarse, w_fine, tau_v, tau_d, device="cuda:0", precision=PREC_BF16, devices=None):
+        rc = cls(cfg, device, precision, devices=devices)
         rc.renderer.load_network(0, w_coarse)
         if w_fine is not None:
             rc.renderer.load_network(1, w_fine)
@@ -441,10 +495,11 @@ class HipRayCaster:
 
 
 
-def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PREC_BF16):
+def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PREC_BF16, devices=None):
     """Counterpart of `create_raycaster` (core/raycasters.py:17-184) for rendering:
-    returns `render_kwargs_test` with the HIP caster under 'ray_caster'."""
-    caster = HipRayCaster(cfg, device, precision)
+    returns `render_kwargs_test` with the HIP caster under 'ray_caster'.  `devices` = the GPUs the
+    reference would hand to nn.DataParallel (raycasters.py:157)."""
+    caster = HipRayCaster(cfg, device, precision, devices=devices)
     if ckpt is not None:
         caster.load_state_dict(ckpt)
     caster.eval()
@@ -456,7 +511,7 @@ def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PR
 _RAYCASTER_CACHE: Dict[tuple, dict] = {}
 
 
-def load_raycaster(ckpt_path: str, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16):
+def load_raycaster(ckpt_path: str, cfg: RenderConfig, device="cuda:0", precision=PREC_BF16, devices=None):
     """`create_raycaster` on an A-NeRF checkpoint file (`.tar`, the reference's five state dicts,
     core/raycasters.py:752-766), memoised on (path, mtime, size, config, device, precision).
 
@@ -467,10 +522,11 @@ def load_raycaster(ckpt_path: str, cfg: RenderConfig, device="cuda:0", precision
     if isinstance(precision, str):
         precision = PREC_BY_NAME[precision]
     st = os.stat(ckpt_path)
-    key = (os.path.abspath(ckpt_path), st.st_mtime_ns, st.st_size, repr(cfg), str(device), int(precision))
+    key = (os.path.abspath(ckpt_path), st.st_mtime_ns, st.st_size, repr(cfg), str(device), int(precision),
+           None if devices is None else tuple(devices))
     kw = _RAYCASTER_CACHE.get(key)
     if kw is None:
         ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
-        kw = create_raycaster(cfg, ckpt, device=device, precision=precision)
+        kw = create_raycaster(cfg, ckpt, device=device, precision=precision, devices=devices)
         _RAYCASTER_CACHE[key] = kw
     return dict(kw)

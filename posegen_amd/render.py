@@ -131,8 +131,54 @@ def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, 
     `frame_ids` (extension) restricts rendering to a subset of frames (multi-GPU
     partition); the returned arrays then hold those frames in the given order.
     """
+    r, _ = _caster_device(render_kwargs["ray_caster"])
+    if getattr(r, "n_devices", 1) > 1 and frame_ids is None and (bg_imgs is None or white_bkgd or bg_indices is None):
+        return _render_path_multi(r, render_poses, hwf, chunk, render_kwargs, centers, kp, skts, cyls, bg_imgs, cams,
+                                  render_factor, white_bkgd, ret_acc, ext_scale)
     rgbs, disps, accs, valid_idxs, bboxes = render_frames_device(
         render_poses, hwf, chunk, render_kwargs, centers=centers, kp=kp, skts=skts, cyls=cyls, bg_imgs=bg_imgs,
         bg_indices=bg_indices, cams=cams, render_factor=render_factor, white_bkgd=white_bkgd, ext_scale=ext_scale,
         frame_ids=frame_ids)
     return (rgbs.cpu().numpy(), disps.cpu().numpy(), accs.cpu().numpy() if ret_acc else [], valid_idxs, bboxes)
+
+
+def _render_path_multi(r, render_poses, hwf, chunk, render_kwargs, centers, kp, skts, cyls, bg_imgs, cams,
+                       render_factor, white_bkgd, ret_acc, ext_scale):
+    """render_path on a caster that owns several GPUs (HipRayCaster(devices=[...])): one pg_render_frames
+    call, frames or ray chunks spread over the devices inside the library (no torch.distributed)."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W = H // render_factor, W // render_factor
+        focal = focal / render_factor if isinstance(focal, float) else focal.copy() / render_factor
+        if centers is not None:
+            centers = centers / render_factor if isinstance(focal, float) else centers.copy() / render_factor
+    if kp is None and cyls is None:
+        raise NotImplementedError("render_path needs kp or cyls (bounding-cylinder cull)")
+    if not (isinstance(H, (int, np.integer)) and isinstance(W, (int, np.integer))):
+        raise ValueError("multi-device render_path needs one frame size (scalar H, W)")
+    cyls, bboxes, grids = kp_to_boxes(render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale,
+                                      centers=centers)
+    valid_idxs = [rows * w + cols for rows, cols, _, w, _, _, _ in grids]
+    F = len(render_poses)
+    n_pose = cyls.shape[0]
+    sk = torch.as_tensor(skts).reshape(-1, 24, 4, 4)
+    sk = torch.stack([sk[i % sk.shape[0]] for i in range(F)])
+    cy = torch.stack([cyls[i % n_pose] for i in range(F)])
+    cm = None
+    if cams is not None:
+        ct = torch.as_tensor(cams).reshape(-1).float()
+        cm = torch.stack([ct[i % ct.shape[0]] for i in range(F)])
+    bg = None
+    if bg_imgs is not None and not white_bkgd:
+        import torch.nn.functional as Fn
+        bgi = torch.tensor(bg_imgs[0])
+        bg = Fn.interpolate(bgi.permute(2, 0, 1)[None].float(), size=(int(H), int(W)), mode="bilinear",
+                            align_corners=False)[0].permute(1, 2, 0).reshape(int(H) * int(W), 3)
+    r.set_chunk(int(chunk))
+    kw = render_kwargs
+    focals = [g[4] for g in grids]
+    rgbs, disps, accs = r.render_frames(int(H), int(W), focals, [g[5] for g in grids], bboxes, sk, cy,
+                                        centers=None if centers is None else [g[6] for g in grids], cams=cm,
+                                        n_samples=kw.get("N_samples"), n_importance=kw.get("N_importance"),
+                                        lindisp=bool(kw.get("lindisp", False)), bg=bg, base_bg=1.0 if white_bkgd else 0.0)
+    return rgbs, disps, accs if ret_acc else [], valid_idxs, bboxes

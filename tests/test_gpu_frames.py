@@ -205,3 +205,33 @@ def test_checkpoint_round_trip_and_cached_loader(tmp_path):
     for k in ("rgb_map", "disp_map", "acc_map"):
         assert torch.equal(x[k], y[k])
     a.renderer.close()
+
+
+@pytest.mark.parametrize("n_frames", [1, 3])
+def test_in_process_multi_device_frames_are_bitwise_those_of_one_device(n_frames):
+    """HipRayCaster(devices=[...]) = the nn.DataParallel replacement (core/raycasters.py:157): render_path
+    spreads whole frames (F >= G) or a frame's ray chunks (F < G) over the devices inside ONE call and
+    must return exactly the single-device frames.  With one GPU the same device is listed twice (two
+    workers, two streams); with more GPUs the real devices are used."""
+    from posegen_amd import surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRayCaster
+    from posegen_amd.render import render_path
+    cfg = surreal_config()
+    model = syn.make_model(cfg, 0)
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if ndev >= 2 else [0, 0]
+    H = W = 96
+    _, kps, skts = syn.make_pose(n_frames, 5)
+    c2ws, focals = syn.make_camera(n_frames, H, W)
+    kw = dict(kp=torch.tensor(kps), skts=torch.tensor(skts), white_bkgd=True, ret_acc=True, ext_scale=cfg.ext_scale)
+    outs = []
+    for devs in (None, devices):
+        c = HipRayCaster.from_weights(cfg, *model, device="cuda:0", precision="fp32", devices=devs)
+        rk = {"ray_caster": c, "N_samples": cfg.n_samples, "N_importance": cfg.n_importance}
+        outs.append(render_path(torch.tensor(c2ws), (H, W, focals), 1024, rk, **kw))     # chunk 1024: several groups per box
+        c.renderer.close()
+    one, multi = outs
+    assert sum(len(v) for v in one[3]) > 2 * 1024 * n_frames / 2
+    for a, b in zip(one[:3], multi[:3]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(np.array(one[4]), np.array(multi[4]))

@@ -191,6 +191,49 @@ def test_render_path_distributed_gloo_world2_fewer_frames_than_ranks(tmp_path):
     _run_world2(tmp_path, _GLOO_RENDER_WORKER)
 
 
+def _plan(n_rays, workers, chunk):
+    import ctypes as C
+    lib = _ffi.load_library()
+    arr = (C.c_int64 * len(n_rays))(*n_rays)
+    n = C.c_int()
+    assert lib.pg_plan_frames(len(n_rays), arr, workers, chunk, None, 0, C.byref(n)) == 0
+    out = (C.c_int32 * (5 * max(n.value, 1)))()
+    assert lib.pg_plan_frames(len(n_rays), arr, workers, chunk, out, n.value, C.byref(n)) == 0
+    return [tuple(out[5 * i:5 * i + 5]) for i in range(n.value)]      # (frame, r0, r1, worker, owner)
+
+
+def test_frame_plan_covers_every_ray_once_on_group_boundaries():
+    """pg_plan_frames (the work plan of the in-process multi-GPU renderer): whole frames by LPT when there
+    are enough of them; otherwise a frame's nanmean groups are cut into contiguous runs, so every cut
+    falls on a multiple of `chunk` and the groups are those of the single-device render."""
+    rng = np.random.RandomState(0)
+    for workers in (1, 2, 3, 8):
+        for F in (1, 2, 5, 20):
+            for chunk in (4096, 1000):
+                n = [int(x) for x in rng.randint(1, 200000, size=F)]
+                tasks = _plan(n, workers, chunk)
+                for f in range(F):
+                    runs = sorted((t[1], t[2]) for t in tasks if t[0] == f)
+                    assert runs[0][0] == 0 and runs[-1][1] == n[f]
+                    for (a0, a1), (b0, b1) in zip(runs, runs[1:]):
+                        assert a1 == b0 and a1 % chunk == 0
+                    owners = {t[4] for t in tasks if t[0] == f}
+                    assert len(owners) == 1 and next(iter(owners)) in {t[3] for t in tasks if t[0] == f}
+                assert all(0 <= t[3] < workers for t in tasks)
+                if F >= workers:
+                    assert all(t[1] == 0 and t[2] == n[t[0]] for t in tasks)          # whole frames
+                    load = [sum(n[t[0]] for t in tasks if t[3] == w) for w in range(workers)]
+                    assert max(load) - min(load) <= max(n)
+                else:
+                    used = {t[3] for t in tasks}
+                    big = [f for f in range(F) if n[f] > chunk * workers]
+                    if len(big) == F:
+                        assert len(used) == workers                                    # nobody idles
+    # one frame, eight devices: eight runs of whole groups
+    t = _plan([262144], 8, 4096)
+    assert [x[2] - x[1] for x in t] == [32768] * 8 and [x[3] for x in t] == list(range(8))
+
+
 def test_bench_launches_itself_for_n_gpus_dry_run():
     """`python bench.py --gpus 2` with no rendezvous in the environment starts its own two
     ranks (as a child process) and relays rank 0's single JSON line; --dry-run swaps the renderer
