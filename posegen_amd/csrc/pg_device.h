@@ -174,6 +174,11 @@ struct Stream {
         return;
 #endif
         if (!dma_wave()) return;
+#if defined(PG_VISIBLE_DMA)     // through the builtin: hipcc counts the piece in its own vmcnt bookkeeping, so its
+        // waits for loads issued a pass ahead come out COUNTED (pg_eval16.hip) instead of vmcnt(0)
+        glds16(wstream + (cur_src + i * 1024) + lane16, ring + cur_dst + i * 1024);
+        return;
+#endif
         const uint8_t* sbase = wstream + (cur_src + i * 1024);      // wave-uniform
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2"
                      :: "s"(ring_lds + cur_dst + i * 1024), "v"(lane16), "s"(sbase) : "memory");

@@ -15,6 +15,9 @@
 // cutoff weight (FACT = false, rays with < 64 samples) or factorised over rays
 // (FACT = true: per-ray Y stage + a K=16 contraction over the joints, pg_layout.h);
 // feature_linear is folded into the view layer by the host packer.
+#ifndef PG_PREFETCH
+#define PG_PREFETCH 1         // global inputs of a pass fetched one pass ahead (see the kernel)
+#endif
 #include "pg_eval16_common.h"
 
 namespace pgd {
@@ -44,10 +47,35 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             *reinterpret_cast<uint4*>(rtf + (i / 512) * SLOTF_BYTES + SLOTF_Y + (i % 512) * 16) = make_uint4(0, 0, 0, 0);
     }
     st.start();
+#if defined(PG_YOUNG_PRIO)
+    // the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what the
+    // older one waits for at the chunk barriers: one static priority for that half (no per-segment flips)
+    if (wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(PG_YOUNG_PRIO);
+#endif
 
 #if defined(PG_STAMPS)
     unsigned long long stamps[12];
 #endif
+    // Inputs of a pass that come from global memory (its z, the Y-stage weights of the wave, the ray / pose
+    // rows of the table builders), fetched one pass ahead.  Issued and consumed inside the prologue, each of
+    // the six dependent loads exposes its L2 latency behind a vmcnt(0); fetched ahead, one wait at the top of
+    // the pass finds them all there.  (That wait still drains the refill pieces issued since: they are inline
+    // asm, invisible to hipcc's vmcnt count.  Making them visible -- PG_VISIBLE_DMA, the builtin -- turns the
+    // wait into a counted one but makes hipcc wait vmcnt(0) before every LDS read of its own, table and bias
+    // loads included, because it then sees LDS writes in flight: far worse.)
+    [[maybe_unused]] float nx_z = 0.0f;
+    [[maybe_unused]] YWeights<V, FC> nx_yw;
+    [[maybe_unused]] TabIn nx_tin{};
+#define PG_PREFETCH_PASS(itn)                                                              \
+    do {                                                                                   \
+        const long long p0n_ = (long long)(itn) * PTS;                                     \
+        const long long plastn_ = min(p0n_ + PTS - 1, a.n_points - 1);                     \
+        const int r0n_ = (int)(p0n_ / a.S);                                                \
+        nx_z = a.z[min(p0n_ + wave * 32 + pt, a.n_points - 1)];                            \
+        nx_yw.load(a, wave, lane);                                                         \
+        ray_tablef_load<FC>(a, r0n_, (int)(plastn_ / a.S) - r0n_ + 1, nx_tin);             \
+    } while (0)
+    if (FACT && PG_PREFETCH && (int)blockIdx.x < a.n_iters) PG_PREFETCH_PASS(blockIdx.x);
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
         PG_STAMP(0);
         const long long p0 = (long long)it * PTS;
@@ -55,6 +83,15 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
         [[maybe_unused]] YWeights<V, FC> yw;
+        [[maybe_unused]] float z_pre = 0.0f;
+        if (FACT && PG_PREFETCH) {
+            yw = nx_yw; z_pre = nx_z;
+            const TabIn tin = nx_tin;
+            lds_barrier();                          // previous pass is done with the table
+            ray_tablef_build<V, FC>(a, tin, rtf, nr);
+            lds_barrier();
+            y_stage<V, FC>(yw, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
+        } else {
         if (FACT) yw.load(a, wave, lane);       // in flight across the barrier and the table build
         lds_barrier();                          // previous pass is done with the table
         if (FACT) {
@@ -66,6 +103,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             lds_barrier();
             ray_table_phase2<NTHR, true>(rtab, nr);
             lds_barrier();
+        }
         }
 
         const long long gp = p0 + wave * 32 + pt;
@@ -81,7 +119,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
         const float* tab = FACT ? nullptr : opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
-        const float zz = (!FACT && a.pts) ? 0.0f : a.z[gpc];
+        const float zz = (FACT && PG_PREFETCH) ? z_pre : (!FACT && a.pts) ? 0.0f : a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
         float px = 0.0f, py = 0.0f, pz = 0.0f;
         if (!FACT) {
@@ -195,6 +233,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         }
         PG_STAMP(7);
         if (TAPS) dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
+        // the next pass's global inputs: in flight through the rgb head and the pass boundary
+        // (unconditional: a conditional re-definition would keep the 100 registers live through the whole pass)
+        if (FACT && PG_PREFETCH) PG_PREFETCH_PASS(min(it + (int)gridDim.x, a.n_iters - 1));
         // ---- rgb head ----
         f32x16 acc = load_bias(bias, BT_RGB, h);
         {

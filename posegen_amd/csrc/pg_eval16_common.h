@@ -305,20 +305,42 @@ static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view 
 //   T16[j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(b), rows e, sin e,
 //   cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:172-193) as 16-bit MFMA
 //   operands, zero padded to 32; joint JC = the ray's frame code.
-template <typename V, bool FC, int NTHREADS>
-__device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
+// The global inputs of one (ray, joint) table entry, fetched a PASS AHEAD (ray_tablef_load at the end of
+// the previous pass, ray_tablef_build at the top of this one): a load issued and consumed inside the
+// prologue can only be waited for with vmcnt(0), which drains the two weight chunks the ring keeps in flight.
+struct TabIn { float4 ra, rb, rc; float ry[6]; float cam; };
+
+template <bool FC>
+__device__ __forceinline__ void ray_tablef_load(const EvalArgs& a, int r0, int nr, TabIn& in) {
     constexpr int NJ = J + (FC ? 1 : 0);
-    for (int idx = threadIdx.x; idx < nr * NJ; idx += NTHREADS) {
+    const int idx = threadIdx.x;                  // nr * NJ <= MAXR_F * 25 entries: one thread each
+    if (idx >= nr * NJ) return;
+    const int rr = idx / NJ, j = idx - rr * NJ;
+    if (j < J) {
+        const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
+        in.ra = sk[0]; in.rb = sk[1]; in.rc = sk[2];
+        const float* ry = a.rays + (long long)(r0 + rr) * 11;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in.ry[k] = ry[k];
+    } else {
+        in.cam = a.cams ? a.cams[r0 + rr] : -1.0f;
+    }
+}
+
+template <typename V, bool FC>
+__device__ __forceinline__ void ray_tablef_build(const EvalArgs& a, const TabIn& in, uint8_t* rt, int nr) {
+    constexpr int NJ = J + (FC ? 1 : 0);
+    const int idx = threadIdx.x;
+    if (idx >= nr * NJ) return;
+    {
         const int rr = idx / NJ, j = idx - rr * NJ;
         uint8_t* slot = rt + rr * SLOTF_BYTES;
         float t[TK];
 #pragma unroll
         for (int k = 0; k < TK; ++k) t[k] = 0.0f;
         if (j < J) {
-            const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
-            const float4 ra = sk[0], rb = sk[1], rc = sk[2];
-            const float* ry = a.rays + (long long)(r0 + rr) * 11;
-            const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
+            const float4 ra = in.ra, rb = in.rb, rc = in.rc;
+            const float ox = in.ry[0], oy = in.ry[1], oz = in.ry[2], dx = in.ry[3], dy = in.ry[4], dz = in.ry[5];
             float e[3];
             e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
             e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
@@ -345,8 +367,8 @@ __device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r
                 }
             }
         } else {
-            const float cf = a.cams ? a.cams[r0 + rr] : -1.0f;
-            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
+            // the code row depends on the (prefetched) index: this one load is waited for in place
+            const int ci = in.cam < 0.0f ? a.n_codes : min((int)in.cam, a.n_codes - 1);
 #pragma unroll
             for (int k = 0; k < FC_CH; ++k) t[k] = a.codes[ci * FC_CH + k];
         }
@@ -354,6 +376,14 @@ __device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r
 #pragma unroll
         for (int q = 0; q < TK / 8; ++q) dst[q] = Op<V>::cvt(t + 8 * q);
     }
+}
+
+template <typename V, bool FC, int NTHREADS>
+__device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
+    static_assert(MAXR_F * (J + 1) <= NTHREADS, "one thread per (ray, joint) table entry");
+    TabIn in{};
+    ray_tablef_load<FC>(a, r0, nr, in);
+    ray_tablef_build<V, FC>(a, in, rt, nr);
 }
 
 // Y stage: Y[ray][j][o] for the rays of this pass.  Wave w: out tile w&3, the 12 (13 with the
@@ -368,7 +398,12 @@ struct YWeights {
     static constexpr int NU = pgp::AF::VY_UNITS(FC);
     uint4 b[NU];
     __device__ __forceinline__ void load(const EvalArgs& a, int wave, int lane) {
-        const uint4* p = reinterpret_cast<const uint4*>(a.wy) + ((size_t)wave * NU) * 64 + lane;
+        // The base is re-defined (opaquely) in every pass: as a loop invariant hipcc forms all NU 64-bit
+        // addresses at kernel entry and keeps them for the whole kernel -- 48 VGPRs, 7 of them spilled,
+        // and every scratch reload waits vmcnt(0), i.e. drains the weight DMA.
+        const uint8_t* wy = a.wy;
+        asm volatile("" : "+s"(wy));
+        const uint4* p = reinterpret_cast<const uint4*>(wy) + ((size_t)wave * NU) * 64 + lane;
 #pragma unroll
         for (int n = 0; n < NU; ++n) b[n] = p[n * 64];
     }
