@@ -207,6 +207,22 @@ int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk
 int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double* bones, const double* bone_offsets,
                        const int32_t* parents, float* kps, float* skts, double* l2ws);
 
+/* Bounding cylinder and its projected integer box per pose, on the device: replaces
+ * get_kp_bounding_cylinder + cylinder_to_box_2d (core/utils/skeleton_utils.py:635-685, 700-787) as
+ * kp_to_valid_rays calls them (core/utils/ray_utils.py:89-104: head '-y', SMPL root joint 0), so that key
+ * points produced on the GPU (pg_pose_kinematics) need not come back to the host before rendering.
+ *   kps    device [n,24,3] f32        w2c  DEVICE [n or 1,4,4] f64 row-major (the reference's float32
+ *          np.linalg.inv(swap_mat(c2w)) widened; w2c_stride = 16, or 0 for one camera)
+ *   ring   DEVICE [50,2] f64: cos, sin of np.linspace(0, 2 pi, 50) as the caller's numpy computes them
+ *   extension = extend_mm * ext_scale; top_ / bot_extension = extension * 1.60 / 1.10 (the caller's doubles)
+ *   fx, fy focal lengths; off_x, off_y = int(W/2), int(H/2) or the integer principal point
+ *   cyls   device [n,5] f32 (cx, cz, radius, top, bot)     boxes device [n,4] i32 (tl_x, tl_y, br_x, br_y)
+ * float32 cylinder, float64 projection, like numpy in the reference; the box is an integer and equals the
+ * reference's on every pose of the golden fixture. */
+int pg_pose_boxes(pg_handle* h, void* stream, int64_t n_poses, const float* kps, const double* w2c, int64_t w2c_stride,
+                  const double* ring, double extension, double top_extension, double bot_extension, double fx, double fy,
+                  int H, int W, int off_x, int off_y, float* cyls, int32_t* boxes);
+
 /* ---- stage entry points (same kernels, exposed for parity tests and profiling) ---- */
 
 /* get_near_far_in_cylinder + sample_from_lineseg (ray_utils.py:204-251, 292-344). */

@@ -47,6 +47,9 @@ extern "C" {
 int pg_launch_frame_rays(const pgk::FrameGeom* g, long long i0, long long n, float* rays, float* cams, void* stream);
 int pg_launch_pose_kinematics(const double* offs72, const int* parents24, const double* bones, long long n,
                               float* kps, float* skts, double* l2ws, void* stream);
+int pg_launch_pose_boxes(const float* kps, long long n, const double* w2c, long long w2c_stride, const double* ring,
+                         float ext_r, float ext_top, float ext_bot, double fx, double fy, int H, int W, int offx, int offy,
+                         float* cyls, int* boxes, void* stream);
 int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map, const float* acc_map,
                             const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8,
                             void* stream);
@@ -805,6 +808,20 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
     rc = frame_render_range(h, stream, g, 0, (int64_t)g.bw * g.bh, skts, cyl, n_samples, n_importance, flags, &maps);
     if (rc) return rc;
     return frame_compose(h, stream, g, maps, bg, base_bg, rgb, disp, acc, rgb8);
+}
+
+int pg_pose_boxes(pg_handle* h, void* stream, int64_t n_poses, const float* kps, const double* w2c, int64_t w2c_stride,
+                  const double* ring, double extension, double top_extension, double bot_extension, double fx, double fy,
+                  int H, int W, int off_x, int off_y, float* cyls, int32_t* boxes) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (n_poses < 0 || !kps || !w2c || !ring || !cyls || !boxes || H <= 0 || W <= 0)
+        return fail(h, PG_EINVAL, "pg_pose_boxes: null/negative argument");
+    if (w2c_stride != 0 && w2c_stride != 16) return fail(h, PG_EINVAL, "pg_pose_boxes: w2c_stride must be 0 (one camera) or 16");
+    PG_HIP(h, hipSetDevice(h->device));
+    int e = pg_launch_pose_boxes(kps, n_poses, w2c, w2c_stride, ring, (float)extension, (float)top_extension, (float)bot_extension,
+                                 fx, fy, H, W, off_x, off_y, cyls, boxes, stream);
+    if (e) return fail(h, PG_EHIP, "pose box kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return PG_OK;
 }
 
 int pg_device_count(const pg_handle* h) { return h ? 1 + (int)h->peers.size() : 0; }

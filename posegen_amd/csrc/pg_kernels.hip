@@ -362,6 +362,56 @@ __global__ __launch_bounds__(256) void frame_compose_kernel(const FrameGeom g, c
     }
 }
 
+// ---- bounding cylinder + projected 2-D box per pose, on the device (residue) ------------
+// get_kp_bounding_cylinder (core/utils/skeleton_utils.py:635-685, head '-y', the constants of
+// kp_to_valid_rays, core/utils/ray_utils.py:89-104) in float32 like numpy on the reference's float32 kp, then
+// cylinder_to_box_2d (skeleton_utils.py:700-787) in float64: 50 points per cap, w2c, pinhole, floor / ceil,
+// principal-point shift, clip.  One thread per pose.  `ring` = cos / sin of np.linspace(0, 2 pi, 50) as the
+// caller's numpy computes them (the box is an integer: everything that feeds floor/ceil is kept in the
+// reference's precision and operation order; the 4-term dot products use one fma chain in k order).
+__global__ __launch_bounds__(64) void pose_boxes_kernel(const float* __restrict__ kps, long long n, const double* __restrict__ w2c,
+                                                       long long w2c_stride, const double* __restrict__ ring, float ext_r,
+                                                       float ext_top, float ext_bot, double fx, double fy, int H, int W,
+                                                       int offx, int offy, float* __restrict__ cyls, int* __restrict__ boxes) {
+    const long long f = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const float* kp = kps + f * 72;
+    const float rx = kp[0], rz = kp[2];
+    float reach = 0.0f, hmax = -__FLT_MAX__, hmin = __FLT_MAX__;
+    for (int j = 0; j < 24; ++j) {
+        const float dx = __fsub_rn(kp[3 * j], rx), dz = __fsub_rn(kp[3 * j + 2], rz);
+        reach = fmaxf(reach, sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dz, dz))));   // sqrtf: correctly rounded (__fsqrt_rn is the native approximation here)
+        const float hgt = -kp[3 * j + 1];                   // head '-y': height = -y
+        hmax = fmaxf(hmax, hgt); hmin = fminf(hmin, hgt);
+    }
+    const float radius = __fadd_rn(reach, ext_r);
+    const float top = -__fadd_rn(hmax, ext_top), bot = -__fsub_rn(hmin, ext_bot);
+    float* c = cyls + f * 5;
+    c[0] = rx; c[1] = rz; c[2] = radius; c[3] = top; c[4] = bot;
+    const double* m = w2c + f * w2c_stride;                  // row-major 4x4 (rows 0..2 used)
+    const double cx = rx, cz = rz, cr = radius;
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int cap = 0; cap < 2; ++cap) {
+        const double y = cap == 0 ? (double)top : (double)bot;
+        for (int k = 0; k < 50; ++k) {
+            const double px = __dadd_rn(cx, __dmul_rn(ring[2 * k], cr)), pz = __dadd_rn(cz, __dmul_rn(ring[2 * k + 1], cr));
+            double q[3];
+            for (int r = 0; r < 3; ++r)
+                q[r] = fma(m[4 * r + 3], 1.0, fma(m[4 * r + 2], pz, fma(m[4 * r + 1], y, __dmul_rn(m[4 * r], px))));
+            const double u = __ddiv_rn(__dmul_rn(q[0], fx), q[2]), v = __ddiv_rn(__dmul_rn(q[1], fy), q[2]);
+            lo[0] = fmin(lo[0], u); hi[0] = fmax(hi[0], u);
+            lo[1] = fmin(lo[1], v); hi[1] = fmax(hi[1], v);
+        }
+    }
+    int* b = boxes + f * 4;
+    const int lim[2] = {W - 1, H - 1}, off[2] = {offx, offy};
+    for (int a = 0; a < 2; ++a) {
+        int tl = (int)floor(lo[a]) + off[a], br = (int)ceil(hi[a]) + off[a];
+        b[a] = min(max(tl, 0), lim[a]);
+        b[2 + a] = min(max(br, 0), lim[a]);
+    }
+}
+
 // ---- batched pose kinematics --------------------------------------
 // get_smpl_l2ws (core/utils/skeleton_utils.py:379-463; run_gan.py:2211-2257): axis-angle ->
 // rotation (scipy's rotvec -> unit quaternion -> matrix map), chain product down the joint
@@ -436,6 +486,15 @@ extern "C" int pg_launch_frame_rays(const pgk::FrameGeom* g, long long i0, long 
     if (n <= 0) return 0;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(pgk::frame_rays_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *g, i0, n, rays, cams);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_launch_pose_boxes(const float* kps, long long n, const double* w2c, long long w2c_stride, const double* ring,
+                                    float ext_r, float ext_top, float ext_bot, double fx, double fy, int H, int W, int offx,
+                                    int offy, float* cyls, int* boxes, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pgk::pose_boxes_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       kps, n, w2c, w2c_stride, ring, ext_r, ext_top, ext_bot, fx, fy, H, W, offx, offy, cyls, boxes);
     return (int)hipGetLastError();
 }
 

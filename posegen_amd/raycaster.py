@@ -337,6 +337,34 @@ class HipRenderer:
                                                 par.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(kps), _ptr(skts), _ptr(l2ws)))
         return (kps, skts, l2ws) if want_l2ws else (kps, skts)
 
+    def pose_boxes(self, kps: torch.Tensor, c2ws, H: int, W: int, focal, ext_scale: float, center=None,
+                   extend_mm: float = 250., top_expand_ratio: float = 1.60, bot_expand_ratio: float = 1.10):
+        """Device bounding cylinders [F,5] f32 and integer boxes [F,4] i32 (tl_x, tl_y, br_x, br_y) of device
+        key points [F,24,3] (pg_pose_boxes: kp_to_valid_rays' cull without the host round trip).  `c2ws`:
+        one camera [4,4] or one per pose [F,4,4] (host); the extrinsic is inverted on the host in float32
+        exactly as the reference does (nerf_c2w_to_extrinsic)."""
+        from .skeleton import nerf_c2w_to_extrinsic
+        kp = _dev_f32(kps.reshape(-1, 24, 3), self.device)
+        F = kp.shape[0]
+        c2w = np.asarray(torch.as_tensor(c2ws).detach().cpu(), dtype=np.float32).reshape(-1, 4, 4)
+        w2c = np.stack([nerf_c2w_to_extrinsic(c) for c in c2w]).astype(np.float64)      # float32 inverse, widened
+        if w2c.shape[0] not in (1, F):
+            raise ValueError(f"{w2c.shape[0]} cameras for {F} poses")
+        phi = np.linspace(0., 2 * np.pi, 50)
+        ring = np.ascontiguousarray(np.stack([np.cos(phi), np.sin(phi)], -1))
+        f = np.asarray(torch.as_tensor(focal).detach().cpu(), dtype=np.float64).reshape(-1)
+        fx, fy = (float(np.float32(f[0])), float(np.float32(f[0]))) if f.size < 2 else (float(np.float32(f[0])), float(np.float32(f[1])))
+        offx, offy = (int(W * .5), int(H * .5)) if center is None else (int(center[0]), int(center[1]))
+        ext = extend_mm * ext_scale
+        d_w2c = torch.tensor(w2c, dtype=torch.float64, device=self.device)
+        d_ring = torch.tensor(ring, dtype=torch.float64, device=self.device)
+        cyls = torch.empty(F, 5, device=self.device)
+        boxes = torch.empty(F, 4, device=self.device, dtype=torch.int32)
+        self._check(self.lib.pg_pose_boxes(self.handle, self._stream(), F, _ptr(kp), _ptr(d_w2c), 16 if w2c.shape[0] > 1 else 0,
+                                           _ptr(d_ring), float(ext), float(ext * top_expand_ratio), float(ext * bot_expand_ratio),
+                                           fx, fy, int(H), int(W), offx, offy, _ptr(cyls), _ptr(boxes)))
+        return cyls, boxes
+
     # -- stage entry points (tests / profiling) ---------------------------------------
     def stage_sample_coarse(self, ray_batch, cyls, n_samples, lindisp=False):
         rb = _dev_f32(ray_batch, self.device)

@@ -235,3 +235,57 @@ def test_in_process_multi_device_frames_are_bitwise_those_of_one_device(n_frames
     for a, b in zip(one[:3], multi[:3]):
         assert a.shape == b.shape and np.array_equal(a, b)
     assert np.array_equal(np.array(one[4]), np.array(multi[4]))
+
+
+def test_pose_boxes_on_device_equal_the_reference_boxes():
+    """pg_pose_boxes: bounding cylinder (float32) and projected integer box (float64) of device key points --
+    bit-for-bit the cylinders and boxes the reference computed for the golden fixture, and those of the host
+    restatement on 500 random poses and cameras."""
+    from posegen_amd import surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRenderer
+    from posegen_amd.rays import kp_to_boxes
+    g = load_golden("valid_rays")
+    H, W = int(g["H"]), int(g["W"])
+    r = HipRenderer(surreal_config(), DEV)
+    cyls, boxes = r.pose_boxes(torch.tensor(g["kps"]), g["c2ws"], H, W, float(g["focals"][0]), 0.001)
+    assert np.array_equal(cyls.cpu().numpy(), g["cyls"])
+    want = np.array([[b[0][0], b[0][1], b[1][0], b[1][1]] for b in g["boxes"]])
+    assert np.array_equal(boxes.cpu().numpy(), want)
+    # random poses, one camera each
+    n = 500
+    _, kps, _ = syn.make_pose(n, 11)
+    rng = np.random.RandomState(3)
+    c2ws, focals = syn.make_camera(n, 512, 512)
+    c2ws = c2ws.copy()
+    c2ws[:, :3, 3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+    hc, hb, _ = kp_to_boxes(torch.tensor(c2ws), 512, 512, focals, kps=torch.tensor(kps), ext_scale=0.001)
+    dc, db = r.pose_boxes(torch.tensor(kps), c2ws, 512, 512, float(focals[0]), 0.001)
+    assert np.array_equal(dc.cpu().numpy(), hc.numpy())
+    assert np.array_equal(db.cpu().numpy(), np.array([[b[0][0], b[0][1], b[1][0], b[1][1]] for b in hb]))
+    r.close()
+
+
+def test_gan_loop_render_call_on_device_equals_the_host_route():
+    """BASELINE config 5: render_for_regressor (kinematics, boxes, frames, crop, normalise, resize all on the
+    device) against the reference-shaped route (numpy kinematics and boxes, render_path, uint8 on the host)."""
+    from posegen_amd import surreal_config, synthetic as syn
+    from posegen_amd.ganloop import render_for_regressor
+    from posegen_amd.raycaster import HipRayCaster
+    from posegen_amd.render import render_path
+    from posegen_amd.skeleton import SURREAL_REST_SCALE, bones_to_pose, smpl_rest_pose
+    cfg = surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=DEV, precision="fp32")
+    H = W = 128
+    rest = smpl_rest_pose * SURREAL_REST_SCALE
+    c2ws, focals = syn.make_camera(3, H, W)
+    bones = syn.make_bones(3, 7)
+    img, frames = render_for_regressor(c, torch.tensor(bones, device=DEV), rest, c2ws[0], H, W, float(focals[0]),
+                                       ext_scale=cfg.ext_scale, crop=(25, 103), out_res=56, return_frames=True)
+    kps, skts, _ = bones_to_pose(bones, rest)
+    rk = {"ray_caster": c, "N_samples": cfg.n_samples, "N_importance": cfg.n_importance}
+    rgbs, *_ = render_path(torch.tensor(c2ws), (H, W, focals), 4096, rk, kp=torch.tensor(kps.astype(np.float32)),
+                           skts=torch.tensor(skts.astype(np.float32)), white_bkgd=True, ext_scale=cfg.ext_scale)
+    assert np.array_equal(frames.cpu().numpy(), (rgbs * 255).astype(np.uint8))
+    assert img.shape == (3, 3, 56, 56) and torch.isfinite(img).all()
+    assert (frames.cpu().numpy() < 255).any(), "something was rendered"
+    c.renderer.close()
