@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 /* error codes */
 #define PG_OK 0
@@ -154,6 +154,45 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
                    const float* skts, int64_t pose_stride,
                    const float* cyls, int64_t cyl_stride, const float* cams,
                    int n_samples, int n_importance, int flags, const pg_outputs* out);
+
+/* The random draws of one training-mode render_rays call (render_kwargs_train,
+ * core/raycasters.py:156-165: perturb, raw_noise_std, ray_noise_std), made by the CALLER:
+ * torch's generator belongs to the host program, and the reference's own deterministic test mode
+ * (pytest=True, ray_utils.py:171-180, 241-244; nerf.py:179-182) overwrites them with fixed numbers
+ * in exactly these places.  All device pointers, any may be NULL (= that term off, as with std 0 /
+ * perturb 0):
+ *   t_rand    [n, N_samples]                  U[0,1): stratified jitter, z = lower + (upper-lower) t
+ *                                             (sample_from_lineseg, ray_utils.py:229-246)
+ *   u_rand    [n, N_importance]               U[0,1): inverse-cdf positions of sample_pdf with
+ *                                             det=False (ray_utils.py:166-170)
+ *   noise0    [n, N_samples]                  added to raw_density / B before the activation in the
+ *                                             coarse raw2outputs (nerf.py:164, 174-184); the caller
+ *                                             scales: randn * raw_noise_std * B
+ *   noise1    [n, N_samples+N_importance]     same for the fine pass (in sorted sample order)
+ *   ray_noise [n, N_samples+N_importance, 3]  position noise randn * ray_noise_std: rows [:N_samples]
+ *                                             of a ray are added to its coarse points
+ *                                             (raycasters.py:660-661), rows [N_samples:] to its
+ *                                             importance points (raycasters.py:673-674); the fine
+ *                                             pass sees every point with the noise it was drawn
+ *                                             with, permuted by the depth sort like the reference's
+ *                                             merged encodings (raycasters.py:458-460)
+ * With ray_noise the per-ray (a + z b) table of the factorised kernels does not apply: both passes
+ * run the direct kernels (q = R (o + z d + noise) + t per point). */
+typedef struct pg_train_draws {
+    const float* t_rand;
+    const float* u_rand;
+    const float* noise0;
+    const float* noise1;
+    const float* ray_noise;
+} pg_train_draws;
+
+/* RayCaster.forward / render_rays in training mode: pg_render_rays with the draws above.
+ * draws == NULL is an error (eval mode is pg_render_rays). */
+int pg_render_rays_train(pg_handle* h, void* stream, int64_t n, const float* ray_batch,
+                         const float* skts, int64_t pose_stride,
+                         const float* cyls, int64_t cyl_stride, const float* cams,
+                         int n_samples, int n_importance, int flags,
+                         const pg_train_draws* draws, const pg_outputs* out);
 
 /* One frame with its front and back end on the device.  Replaces, per
  * frame: get_rays + the bounding-box gather of kp_to_valid_rays (core/utils/ray_utils.py:6-28,

@@ -308,12 +308,20 @@ def near_far_in_cylinder(rays_o, rays_d, cyl, near, far):
     return new_near, new_far
 
 
-def coarse_z(near, far, n_samples: int, lindisp: bool = False):
-    """Deterministic (perturb=0) depth samples (ray_utils.py:204-251)."""
+def coarse_z(near, far, n_samples: int, lindisp: bool = False, t_rand=None):
+    """Depth samples (ray_utils.py:204-251): deterministic with perturb=0, else stratified
+    with the uniform draws `t_rand` [n,S] the reference makes at ray_utils.py:238-244."""
     t = torch.linspace(0., 1., steps=n_samples).expand(near.shape[0], n_samples)
     if lindisp:
-        return 1. / (1. / near * (1. - t) + 1. / far * t)
-    return near * (1. - t) + far * t
+        z = 1. / (1. / near * (1. - t) + 1. / far * t)
+    else:
+        z = near * (1. - t) + far * t
+    if t_rand is not None:
+        mids = .5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * t_rand
+    return z
 
 
 # ----------------------------------------------------------------------------
@@ -421,12 +429,13 @@ def _run_mlp(x, weights, cfg, netchunk=65536):
 # ----------------------------------------------------------------------------
 # a-13: alpha compositing
 # ----------------------------------------------------------------------------
-def composite(raw, z, rays_d, cfg: OracleConfig):
-    """raw [n,S,4], z [n,S], rays_d [n,3] (nerf.py:150-205, eval: no noise)."""
+def composite(raw, z, rays_d, cfg: OracleConfig, noise=None):
+    """raw [n,S,4], z [n,S], rays_d [n,3] (nerf.py:150-205); `noise` [n,S] = the term the
+    reference adds before the activation when raw_noise_std > 0 (nerf.py:174-184), else 0."""
     delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
     delta = delta * torch.norm(rays_d[:, None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3]) * (1 + 2 * cfg.rgb_eps) - cfg.rgb_eps
-    alpha = 1. - torch.exp(-F.relu(raw[..., 3] / cfg.density_scale + 0.) * delta)
+    alpha = 1. - torch.exp(-F.relu(raw[..., 3] / cfg.density_scale + (0. if noise is None else noise)) * delta)
     trans = torch.cumprod(torch.cat([torch.ones(z.shape[0], 1), 1. - alpha + 1e-10], -1), -1)[:, :-1]
     w = alpha * trans
     rgb_map = torch.sum(w[..., None] * rgb, -2)
@@ -441,14 +450,18 @@ def composite(raw, z, rays_d, cfg: OracleConfig):
 # ----------------------------------------------------------------------------
 # a-14: deterministic importance samples
 # ----------------------------------------------------------------------------
-def importance_z(z, weights, n_importance: int):
-    """Inverse-CDF samples at u=linspace(0,1,N) over the interior coarse bins,
-    merged with the coarse depths (ray_utils.py:157-201, 255-289; det=True)."""
+def importance_z(z, weights, n_importance: int, u_rand=None):
+    """Inverse-CDF samples over the interior coarse bins merged with the coarse depths
+    (ray_utils.py:157-201, 255-289): at u=linspace(0,1,N) (det=True) or at the caller's
+    uniform draws `u_rand` [n,N] (det=False, ray_utils.py:166-180)."""
     mids = .5 * (z[:, 1:] + z[:, :-1])
     pw = weights[:, 1:-1] + 1e-5
     pdf = pw / torch.sum(pw, -1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
-    u = torch.linspace(0., 1., steps=n_importance).expand(cdf.shape[0], n_importance).contiguous()
+    if u_rand is None:
+        u = torch.linspace(0., 1., steps=n_importance).expand(cdf.shape[0], n_importance).contiguous()
+    else:
+        u = u_rand.contiguous()
     hi = torch.searchsorted(cdf, u, right=True)
     lo = torch.clamp(hi - 1, min=0)
     hi = torch.clamp(hi, max=cdf.shape[-1] - 1)
@@ -466,33 +479,45 @@ def importance_z(z, weights, n_importance: int):
 # ----------------------------------------------------------------------------
 def render_rays(ray_batch, skts, cyls, cfg: OracleConfig, w_coarse, w_fine,
                 n_samples: int, n_importance: int, cams=None, lindisp=False,
-                return_extras: bool = False):
-    """One `RayCaster.render_rays` call in eval mode (raycasters.py:361-474).
+                return_extras: bool = False, draws: Optional[Dict[str, torch.Tensor]] = None):
+    """One `RayCaster.render_rays` call (raycasters.py:361-474).
 
     ray_batch [n,11] = (o, d, near, far, viewdir); skts [n|1,J,4,4]; cyls [n|1,5].
+    `draws` = None: eval mode (perturb = noise = 0).  Otherwise the random numbers of a
+    training-mode call, any subset of: t_rand [n,S] (ray_utils.py:238-244), u_rand [n,N]
+    (ray_utils.py:166-180), noise0 [n,S] / noise1 [n,S+N] (nerf.py:174-184, already scaled),
+    ray_noise [n,S+N,3] (raycasters.py:660-661 rows [:S], 673-674 rows [S:], already scaled).
     """
+    draws = draws or {}
     n = ray_batch.shape[0]
     o, d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     near0, far0 = ray_batch[:, 6:7], ray_batch[:, 7:8]
     if cyls.shape[0] < n:
         cyls = cyls.expand(n, -1)
     near, far = near_far_in_cylinder(o, d, cyls, near0, far0)
-    z = coarse_z(near, far, n_samples, lindisp)
+    z = coarse_z(near, far, n_samples, lindisp, draws.get("t_rand"))
     pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    rn = draws.get("ray_noise")
+    if rn is not None:
+        pts = pts + rn[:, :n_samples]
     x = embed_points(pts, d, skts, cfg, cams)
     raw = _run_mlp(x, w_coarse, cfg)
-    out_c = composite(raw, z, d, cfg)
+    out_c = composite(raw, z, d, cfg, draws.get("noise0"))
     extras = {"near": near, "far": far, "z_coarse": z, "raw_coarse": raw,
               "weights_coarse": out_c["weights"]}
     if return_extras:
         extras["x_coarse"] = x
     out = out_c
     if n_importance > 0:
-        z_all, z_new, order = importance_z(z, out_c["weights"], n_importance)
+        z_all, z_new, order = importance_z(z, out_c["weights"], n_importance, draws.get("u_rand"))
         pts_f = o[:, None, :] + d[:, None, :] * z_all[..., None]
+        if rn is not None:
+            # the reference embeds the noisy coarse and importance points separately and merges the
+            # encodings by the depth sort (raycasters.py:451-460): every point keeps its own draw
+            pts_f = pts_f + torch.gather(rn, 1, order[..., None].expand(-1, -1, 3))
         x_f = embed_points(pts_f, d, skts, cfg, cams)
         raw_f = _run_mlp(x_f, w_fine, cfg)
-        out = composite(raw_f, z_all, d, cfg)
+        out = composite(raw_f, z_all, d, cfg, draws.get("noise1"))
         extras.update({"z_fine": z_all, "z_new": z_new, "order": order, "raw_fine": raw_f})
     ret = {"rgb_map": out["rgb_map"], "disp_map": out["disp_map"],
            "acc_map": out["acc_map"], "alpha": out["alpha"]}

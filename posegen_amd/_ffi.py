@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
-PG_ABI_VERSION = 3
+PG_ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -42,6 +42,11 @@ class PgConfig(C.Structure):
 _FP = C.c_void_p  # device float*
 
 
+class PgTrainDraws(C.Structure):
+    """pg_train_draws: the caller's random numbers of one training-mode call."""
+    _fields_ = [(k, _FP) for k in ("t_rand", "u_rand", "noise0", "noise1", "ray_noise")]
+
+
 class PgOutputs(C.Structure):
     _fields_ = [(k, _FP) for k in ("rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0",
                                    "alpha0", "near_far", "z_coarse", "z_fine", "raw_coarse", "raw_fine",
@@ -61,6 +66,8 @@ PROTOTYPES = {
     "pg_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
                                  C.c_int, C.c_int, C.c_int, C.POINTER(PgOutputs)]),
+    "pg_render_rays_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
+                                       C.c_int, C.c_int, C.c_int, C.POINTER(PgTrainDraws), C.POINTER(PgOutputs)]),
     "pg_stage_sample_coarse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, C.c_int,
                                          C.c_int, _FP, _FP]),
     "pg_stage_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, _FP, _FP, _FP,

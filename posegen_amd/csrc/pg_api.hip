@@ -28,10 +28,12 @@ int pg_eval32_points_per_pass(void);
 int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream);
 int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
-                            int S, int lindisp, float* near_far, float* z, void* stream);
+                            int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
+int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
                         float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
-                        float* weights, int n_imp, float* z_fine, void* stream);
+                        float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
+                        void* stream);
 int pg_composite_max_samples(void);
 int pg_composite_max_importance(void);
 }
@@ -249,10 +251,11 @@ int check_ready(pg_handle* h, bool need_fine) {
 
 int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
                 const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
-                const float* points = nullptr) {
+                const float* points = nullptr, const float* pnoise = nullptr) {
     const int prec = h->cfg.precision;
-    const bool compk = use_comp_kernel(prec, S, points != nullptr);
-    const bool fact = compk || (!points && use_fact(prec, S));      // explicit points: the direct kernel (q = R p + t)
+    // explicit points and position noise need q = R p + t per point: the direct kernels (no per-ray a + z b table)
+    const bool compk = !pnoise && use_comp_kernel(prec, S, points != nullptr);
+    const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const bool small = fact && use_small_tiles();
@@ -261,7 +264,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
-    a.rays = rays; a.z = z; a.pts = points; a.skts = skts; a.cams = cams;
+    a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
     a.wstream = small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
     a.wy = (fact && !compk) ? ns.d_vy[prec] : nullptr;
@@ -596,7 +599,7 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
     if (cyl_stride != 0 && cyl_stride != 5) return fail(h, PG_EINVAL, "cyl_stride must be 0 or 5");
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, n_samples,
-                                    (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, stream);
+                                    (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, nullptr, stream);
     if (e) return fail(h, PG_EHIP, "sample_coarse launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
@@ -643,14 +646,36 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, con
     if (n_importance > 0 && n_samples < 3) return fail(h, PG_EINVAL, "importance sampling needs N_samples >= 3");
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_composite(ray_batch, z, raw, n, n_samples, h->cfg.density_scale, h->cfg.rgb_eps, rgb, disp, acc,
-                                alpha, weights, n_importance, z_fine, stream);
+                                alpha, weights, n_importance, z_fine, nullptr, nullptr, nullptr, stream);
     if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
+}
+
+namespace {
+int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
+                     int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
+                     int n_importance, int flags, const pg_train_draws* dr, const pg_outputs* out);
 }
 
 int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
                    int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
                    int n_importance, int flags, const pg_outputs* out) {
+    return render_rays_impl(h, stream, n, ray_batch, skts, pose_stride, cyls, cyl_stride, cams, n_samples, n_importance,
+                            flags, nullptr, out);
+}
+
+int pg_render_rays_train(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
+                         int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
+                         int n_importance, int flags, const pg_train_draws* draws, const pg_outputs* out) {
+    if (!draws) return fail(h, PG_EINVAL, "pg_render_rays_train: null draws (use pg_render_rays for eval mode)");
+    return render_rays_impl(h, stream, n, ray_batch, skts, pose_stride, cyls, cyl_stride, cams, n_samples, n_importance,
+                            flags, draws, out);
+}
+
+namespace {
+int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
+                     int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
+                     int n_importance, int flags, const pg_train_draws* dr, const pg_outputs* out) {
     int rc = check_ready(h, n_importance > 0);
     if (rc) return rc;
     if (n < 0 || !ray_batch || !skts || !cyls || !out) return fail(h, PG_EINVAL, "pg_render_rays: null/negative argument");
@@ -668,31 +693,49 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
     const size_t b_nf = al((size_t)n * 2 * 4), b_zc = al((size_t)n * S * 4), b_rc = al((size_t)n * S * 16),
                  b_w0 = al((size_t)n * S * 4), b_zf = al((size_t)n * SF * 4), b_rf = al((size_t)n * SF * 16);
-    rc = ensure_ws(h, b_nf + b_zc + b_rc + b_w0 + (n_importance > 0 ? b_zf + b_rf : 0));
+    const bool hier = n_importance > 0;
+    const bool rnoise = dr && dr->ray_noise;
+    const size_t b_ord = rnoise && hier ? al((size_t)n * SF * 4) : 0, b_pn = rnoise ? al((size_t)n * SF * 12) : 0;
+    rc = ensure_ws(h, b_nf + b_zc + b_rc + b_w0 + (hier ? b_zf + b_rf : 0) + b_ord + b_pn);
     if (rc) return rc;
     uint8_t* p = h->ws;
     float* nf = reinterpret_cast<float*>(p); p += b_nf;
     float* zc = reinterpret_cast<float*>(p); p += b_zc;
     float* rawc = reinterpret_cast<float*>(p); p += b_rc;
     float* w0 = reinterpret_cast<float*>(p); p += b_w0;
-    float* zf = reinterpret_cast<float*>(p); p += b_zf;
-    float* rawf = reinterpret_cast<float*>(p);
+    float* zf = reinterpret_cast<float*>(p); p += hier ? b_zf : 0;
+    float* rawf = reinterpret_cast<float*>(p); p += hier ? b_rf : 0;
+    int* order = b_ord ? reinterpret_cast<int*>(p) : nullptr; p += b_ord;
+    float* pn = b_pn ? reinterpret_cast<float*>(p) : nullptr;
 
-    rc = pg_stage_sample_coarse(h, stream, n, ray_batch, cyls, cyl_stride, S, flags, nf, zc);
+    // near/far + coarse depths; with perturb the stratified jitter from the caller's draws (ray_utils.py:229-246)
+    {
+        int e0 = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, S, (flags & PG_FLAG_LINDISP) ? 1 : 0, nf, zc,
+                                         dr ? dr->t_rand : nullptr, stream);
+        if (e0) return fail(h, PG_EHIP, "coarse sampling launch failed: %s", hipGetErrorString((hipError_t)e0));
+    }
+    if (rnoise) {       // position noise of the coarse points: rows [:S] of every ray's draws
+        int e0 = pg_launch_gather_noise(dr->ray_noise, n, SF, S, nullptr, pn, stream);
+        if (e0) return fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e0));
+    }
+    rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr, 0, nullptr, rnoise ? pn : nullptr);
     if (rc) return rc;
-    rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr);
-    if (rc) return rc;
-    const bool hier = n_importance > 0;
     int e = pg_launch_composite(ray_batch, zc, rawc, n, S, h->cfg.density_scale, h->cfg.rgb_eps,
                                 hier ? out->rgb0 : out->rgb_map, hier ? out->disp0 : out->disp_map,
                                 hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
-                                out->weights0 ? out->weights0 : w0, n_importance, hier ? zf : nullptr, stream);
+                                out->weights0 ? out->weights0 : w0, n_importance, hier ? zf : nullptr,
+                                dr ? dr->noise0 : nullptr, dr ? dr->u_rand : nullptr, order, stream);
     if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     if (hier) {
-        rc = launch_eval(h, stream, 1, n, SF, ray_batch, zf, skts, pose_stride, cams, rawf, nullptr);
+        if (rnoise) {   // every fine point keeps the noise of the stage it came from, in sorted order (raycasters.py:666-686)
+            e = pg_launch_gather_noise(dr->ray_noise, n, SF, SF, order, pn, stream);
+            if (e) return fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
+        rc = launch_eval(h, stream, 1, n, SF, ray_batch, zf, skts, pose_stride, cams, rawf, nullptr, 0, nullptr, rnoise ? pn : nullptr);
         if (rc) return rc;
         e = pg_launch_composite(ray_batch, zf, rawf, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, out->rgb_map,
-                                out->disp_map, out->acc_map, out->alpha, nullptr, 0, nullptr, stream);
+                                out->disp_map, out->acc_map, out->alpha, nullptr, 0, nullptr, dr ? dr->noise1 : nullptr,
+                                nullptr, nullptr, stream);
         if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     // optional intermediates
@@ -703,6 +746,7 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
     if (hier && out->raw_fine) PG_HIP(h, hipMemcpyAsync(out->raw_fine, rawf, (size_t)n * SF * 16, hipMemcpyDeviceToDevice, s));
     return PG_OK;
 }
+}  // namespace
 
 int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double* bones, const double* bone_offsets,
                        const int32_t* parents, float* kps, float* skts, double* l2ws) {

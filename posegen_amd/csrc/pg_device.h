@@ -18,6 +18,7 @@ struct EvalArgs {
     const float* rays;        // [n,11] ray_batch rows (o, d, near, far, viewdir): o,d used
     const float* z;           // [n,S]  depths of the points p = o + d z
     const float* pts;         // density query: explicit points [n_points,3] instead of o + d z (else null)
+    const float* pnoise;      // training (ray_noise_std): position noise [n_points,3] added to o + d z (else null)
     const float* skts;        // [*,24,4,4]
     const float* cams;        // [n] frame-code index (float) or null
     const float* codes;       // [n_codes+1,16], last row = mean code; null if no frame code

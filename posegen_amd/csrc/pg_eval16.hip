@@ -129,6 +129,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
                 px = __fadd_rn(od[0], __fmul_rn(od[3], zz));
                 py = __fadd_rn(od[1], __fmul_rn(od[4], zz));
                 pz = __fadd_rn(od[2], __fmul_rn(od[5], zz));
+                if (a.pnoise) {     // pts + randn_like(pts) * ray_noise_std (raycasters.py:660-661)
+                    px = __fadd_rn(px, a.pnoise[gpc * 3]); py = __fadd_rn(py, a.pnoise[gpc * 3 + 1]); pz = __fadd_rn(pz, a.pnoise[gpc * 3 + 2]);
+                }
             }
         }
         const QFromRows q_rows{skb, px, py, pz};

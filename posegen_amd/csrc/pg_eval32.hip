@@ -217,9 +217,12 @@ __global__ __launch_bounds__(NTHR_B, 1) void eval32_kernel(const EvalArgs a) {
         const float* slot = rtab + ((int)(gpc / a.S) - r0) * SLOT_FLOATS;
         const float zz = a.pts ? 0.0f : a.z[gpc];
         // explicit points (pg_query_density) or p = o + d z as the reference forms it (mul, then add)
-        const float px = a.pts ? a.pts[gpc * 3 + 0] : __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
-        const float py = a.pts ? a.pts[gpc * 3 + 1] : __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
-        const float pz = a.pts ? a.pts[gpc * 3 + 2] : __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
+        float px = a.pts ? a.pts[gpc * 3 + 0] : __fadd_rn(slot[SLOT_O + 0], __fmul_rn(slot[SLOT_D + 0], zz));
+        float py = a.pts ? a.pts[gpc * 3 + 1] : __fadd_rn(slot[SLOT_O + 1], __fmul_rn(slot[SLOT_D + 1], zz));
+        float pz = a.pts ? a.pts[gpc * 3 + 2] : __fadd_rn(slot[SLOT_O + 2], __fmul_rn(slot[SLOT_D + 2], zz));
+        if (a.pnoise) {     // pts + randn_like(pts) * ray_noise_std (raycasters.py:660-661)
+            px = __fadd_rn(px, a.pnoise[gpc * 3]); py = __fadd_rn(py, a.pnoise[gpc * 3 + 1]); pz = __fadd_rn(pz, a.pnoise[gpc * 3 + 2]);
+        }
 
         float act[HSEQ];
         f32x16 acc[NT];

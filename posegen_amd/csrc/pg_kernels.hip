@@ -44,7 +44,7 @@ __device__ __forceinline__ void ray_near_far(const float* rb, const float* cyl, 
 __global__ __launch_bounds__(SC_THREADS) void sample_coarse_kernel(
         const float* __restrict__ rays, const float* __restrict__ cyls, long long cyl_stride,
         long long n, int chunk, int S, int lindisp,
-        float* __restrict__ near_far, float* __restrict__ z) {
+        float* __restrict__ near_far, float* __restrict__ z, const float* __restrict__ t_rand) {
     __shared__ double red[3][SC_THREADS / 64][2];
     __shared__ float fix[2];
     __shared__ int any_nan;
@@ -118,6 +118,19 @@ __global__ __launch_bounds__(SC_THREADS) void sample_coarse_kernel(
             }
             zr[s] = zv;
         }
+        if (t_rand) {
+            // perturb > 0 (ray_utils.py:229-246): a stratified sample in [lower, upper] of every depth, the
+            // uniform draws t_rand [n,S] supplied by the caller; in place, neighbours read before they change
+            const float* tr = t_rand + r * S;
+            float prev = zr[0], cur = zr[0];
+            for (int s = 0; s < S; ++s) {
+                const float nxt = s + 1 < S ? zr[s + 1] : cur;
+                const float lower = s == 0 ? cur : __fmul_rn(0.5f, __fadd_rn(cur, prev));
+                const float upper = s + 1 < S ? __fmul_rn(0.5f, __fadd_rn(nxt, cur)) : cur;
+                zr[s] = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
+                prev = cur; cur = nxt;
+            }
+        }
     }
 }
 
@@ -172,7 +185,8 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
         long long n, int S, float density_scale, float rgb_eps,
         float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
         float* __restrict__ alpha_out, float* __restrict__ w_out,
-        int n_imp, float* __restrict__ z_fine) {
+        int n_imp, float* __restrict__ z_fine, const float* __restrict__ noise, const float* __restrict__ u_rand,
+        int* __restrict__ order) {
     __shared__ float sh_w[CP_WAVES][CP_MAXS];
     __shared__ float sh_z[CP_WAVES][CP_MAXS + CP_MAXI];
     __shared__ float sh_cdf[CP_WAVES][CP_MAXS];
@@ -195,7 +209,8 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
             const float4 q = rr[s];
             const float zs = zr[s];
             const float delta = (s + 1 < S ? zr[s + 1] - zs : 1e10f) * dnorm;
-            const float sig = fmaxf(q.w / density_scale + 0.0f, 0.0f);
+            // raw2alpha(raw / B + noise): `noise` [n,S] is the caller's draw (training, nerf.py:175-186), else 0
+            const float sig = fmaxf(q.w / density_scale + (noise ? noise[ray * S + s] : 0.0f), 0.0f);
             a_[e] = 1.0f - expf(-sig * delta);
             z_[e] = zs;
             const float k = 1.0f + 2.0f * rgb_eps;
@@ -262,7 +277,9 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
     for (int k = lane; k < n_imp; k += 64) {
         // torch.linspace(0,1,n_imp)
         const float stepu = 1.0f / (float)(n_imp - 1);
-        const float u = k < n_imp / 2 ? stepu * (float)k : 1.0f - stepu * (float)(n_imp - 1 - k);
+        // det = (perturb == 0): linspace; otherwise the caller's uniform draws u_rand [n,n_imp] (ray_utils.py:166-170)
+        const float u = u_rand ? u_rand[ray * n_imp + k]
+                               : (k < n_imp / 2 ? stepu * (float)k : 1.0f - stepu * (float)(n_imp - 1 - k));
         // searchsorted(cdf, u, right=True): first index with cdf > u
         int lo = 0, hi = NC;
         while (lo < hi) {
@@ -289,6 +306,21 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
             rank += (y < x || (y == x && j < i)) ? 1 : 0;
         }
         z_fine[ray * NTOT + rank] = x;
+        if (order) order[ray * NTOT + rank] = i;       // sorted_idxs of torch.sort(cat([z, z_samples]))
+    }
+}
+
+// ray_noise_std > 0 (raycasters.py:660-661, 673-674): the position noise of the points of one pass in the order
+// the eval kernel walks them.  src [n,stride,3] holds the caller's draws in the reference's pre-sort order
+// (coarse points first, importance points after); order = the sort permutation (or null: identity).
+__global__ __launch_bounds__(256) void gather_noise_kernel(const float* __restrict__ src, long long n, int stride, int S,
+                                                          const int* __restrict__ order, float* __restrict__ dst) {
+    const long long tot = n * S;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const long long ray = i / S;
+        const int k = order ? order[i] : (int)(i - ray * S);
+        const float* q = src + (ray * stride + k) * 3;
+        dst[i * 3] = q[0]; dst[i * 3 + 1] = q[1]; dst[i * 3 + 2] = q[2];
     }
 }
 
@@ -511,23 +543,32 @@ extern "C" int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb
 
 extern "C" int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride,
                                        long long n, int chunk, int S, int lindisp,
-                                       float* near_far, float* z, void* stream) {
+                                       float* near_far, float* z, const float* t_rand, void* stream) {
     if (n <= 0) return 0;
     const long long blocks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL(pgk::sample_coarse_kernel, dim3((unsigned)blocks), dim3(pgk::SC_THREADS), 0,
                        static_cast<hipStream_t>(stream), rays, cyls, cyl_stride, n, chunk, S, lindisp,
-                       near_far, z);
+                       near_far, z, t_rand);
     return (int)hipGetLastError();
 }
 
 extern "C" int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
                                    float density_scale, float rgb_eps, float* rgb, float* disp, float* acc,
-                                   float* alpha, float* weights, int n_imp, float* z_fine, void* stream) {
+                                   float* alpha, float* weights, int n_imp, float* z_fine, const float* noise,
+                                   const float* u_rand, int* order, void* stream) {
     if (n <= 0) return 0;
     const long long blocks = (n + pgk::CP_WAVES - 1) / pgk::CP_WAVES;
     hipLaunchKernelGGL(pgk::composite_kernel, dim3((unsigned)blocks), dim3(pgk::CP_WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), rays, z, reinterpret_cast<const float4*>(raw), n, S,
-                       density_scale, rgb_eps, rgb, disp, acc, alpha, weights, n_imp, z_fine);
+                       density_scale, rgb_eps, rgb, disp, acc, alpha, weights, n_imp, z_fine, noise, u_rand, order);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream) {
+    if (n <= 0) return 0;
+    const long long tot = n * S;
+    const unsigned blocks = (unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pgk::gather_noise_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, n, stride, S, order, dst);
     return (int)hipGetLastError();
 }
 

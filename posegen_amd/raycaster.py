@@ -7,7 +7,9 @@ core/trainer.py:74: same call signature, same returned dict keys
 (`_collect_outputs`, raycasters.py:711-724), same checkpoint key scheme
 (`state_dict` / `load_state_dict`, raycasters.py:752-788).
 
-Inference (eval-mode, `perturb == 0`) only: training-mode arguments raise.
+Forward values only (no autograd graph).  Eval mode is the measured path; the training-mode
+arguments (perturb, raw_noise_std, ray_noise_std, pytest) are honoured with the random numbers
+drawn on the host side of the ABI (`training_draws`, pg_train_draws).
 """
 from __future__ import annotations
 
@@ -170,7 +172,11 @@ class HipRenderer:
     def render_rays(self, ray_batch: torch.Tensor, skts: torch.Tensor, cyls: torch.Tensor,
                     cams: Optional[torch.Tensor] = None, n_samples: Optional[int] = None,
                     n_importance: Optional[int] = None, lindisp: bool = False,
-                    want_alpha: bool = True, extras: bool = False) -> Dict[str, torch.Tensor]:
+                    want_alpha: bool = True, extras: bool = False,
+                    draws: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """One `RayCaster.render_rays` call (core/raycasters.py:361-474).  `draws` = None: eval mode.
+        Otherwise the random numbers of a training-mode call (pg_train_draws, posegen_hip.h): any of
+        t_rand [n,S], u_rand [n,N], noise0 [n,S], noise1 [n,S+N], ray_noise [n,S+N,3]."""
         cfg = self.cfg
         S = cfg.n_samples if n_samples is None else int(n_samples)
         N = cfg.n_importance if n_importance is None else int(n_importance)
@@ -210,7 +216,25 @@ class HipRenderer:
         for k in ("near_far", "z_coarse", "z_fine", "raw_coarse", "raw_fine", "weights0"):
             setattr(po, k, ex[k].data_ptr() if k in ex else None)
         flags = _ffi.PG_FLAG_LINDISP if lindisp else 0
-        if n > 0:
+        if draws:
+            shapes = {"t_rand": (n, S), "u_rand": (n, N), "noise0": (n, S), "noise1": (n, SF), "ray_noise": (n, SF, 3)}
+            unknown = set(draws) - set(shapes)
+            if unknown:
+                raise ValueError(f"unknown draws {sorted(unknown)}; expected a subset of {sorted(shapes)}")
+            pd, keep = _ffi.PgTrainDraws(), []
+            for k, shp in shapes.items():
+                t = draws.get(k)
+                if t is None or (N == 0 and k in ("u_rand", "noise1")):
+                    continue
+                t = _dev_f32(t, dev)
+                if tuple(t.shape) != shp:
+                    raise ValueError(f"draws[{k!r}] must be {shp}, got {tuple(t.shape)}")
+                keep.append(t)
+                setattr(pd, k, t.data_ptr())
+            if n > 0:
+                self._check(self.lib.pg_render_rays_train(self.handle, self._stream(), n, _ptr(rb), _ptr(sk), ps, _ptr(cy),
+                                                          cs, _ptr(cam), S, N, flags, C.byref(pd), C.byref(po)))
+        elif n > 0:
             self._check(self.lib.pg_render_rays(self.handle, self._stream(), n, _ptr(rb), _ptr(sk), ps, _ptr(cy), cs,
                                                 _ptr(cam), S, N, flags, C.byref(po)))
         if extras:
@@ -504,11 +528,15 @@ class HipRayCaster:
                 cams=None, subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0,
                 network_fine=None, raw_noise_std=0., ray_noise_std=0., verbose=False, ext_scale=0.001,
                 pytest=False, preproc_kwargs=None, nerf_type="nerf", fwd_type="", use_viewdirs=True,
-                want_alpha=True, extras=False, **unused):
+                want_alpha=True, extras=False, draws=None, **unused):
+        """`RayCaster.forward` (core/raycasters.py:349-474), forward values only (no autograd graph:
+        SURVEY.md 8 scopes the renderer, not NeRF training).  perturb / raw_noise_std /
+        ray_noise_std behave as in render_kwargs_train (raycasters.py:156-165): the random numbers
+        come from torch's generator on the caster's device, from numpy after np.random.seed(0) when
+        pytest=True (the reference's deterministic test mode; it has no override for the position
+        noise, which stays a torch draw), or from `draws` when the caller supplies them."""
         if fwd_type:
             raise NotImplementedError(f"fwd_type={fwd_type!r} is not on the HIP path ('density' and 'mesh' are)")
-        if self.training or perturb or raw_noise_std or ray_noise_std:
-            raise NotImplementedError("HipRayCaster renders in eval mode only (perturb = noise = 0)")
         if subject_idxs is not None:
             raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
         if skts is None or cyls is None:
@@ -517,10 +545,47 @@ class HipRayCaster:
         # (ray_utils.py:292-344): only batchify_rays / render_path split a frame into `chunk` groups.
         if not getattr(self, "_grouped_call", False):
             self.renderer.set_chunk(max(int(ray_batch.shape[0]), 1))
+        if draws is None and (perturb or raw_noise_std or ray_noise_std):
+            S = self.cfg.n_samples if N_samples is None else int(N_samples)
+            draws = self.training_draws(int(ray_batch.shape[0]), S, int(N_importance or 0), perturb, raw_noise_std,
+                                        ray_noise_std, pytest=pytest)
         return self.renderer.render_rays(ray_batch, skts, cyls, cams=cams, n_samples=N_samples,
                                          n_importance=N_importance, lindisp=bool(lindisp),
-                                         want_alpha=want_alpha, extras=extras)
+                                         want_alpha=want_alpha, extras=extras, draws=draws)
 
+    def training_draws(self, n, S, N, perturb=0., raw_noise_std=0., ray_noise_std=0., pytest=False):
+        return make_training_draws(n, S, N, perturb, raw_noise_std, ray_noise_std, pytest=pytest,
+                                   density_scale=self.cfg.density_scale, device=self.renderer.device)
+
+
+def make_training_draws(n, S, N, perturb=0., raw_noise_std=0., ray_noise_std=0., pytest=False,
+                        density_scale=1., device="cpu"):
+    """The random numbers one training-mode render_rays call consumes, in the reference's
+    places: t_rand (ray_utils.py:238-244), u_rand (ray_utils.py:166-180), the density noise
+    randn * raw_noise_std * B of both passes (nerf.py:174-182; pytest: rand * raw_noise_std,
+    numpy, no B) and the position noise randn * ray_noise_std (raycasters.py:660-661, 673-674)."""
+    dev = device
+    d = {}
+    f32 = lambda a: torch.Tensor(a).to(dev)
+    if perturb and perturb > 0.:
+        if pytest:
+            np.random.seed(0); d["t_rand"] = f32(np.random.rand(n, S))
+            if N > 0:
+                np.random.seed(0); d["u_rand"] = f32(np.random.rand(n, N))
+        else:
+            d["t_rand"] = torch.rand(n, S, device=dev)
+            if N > 0:
+                d["u_rand"] = torch.rand(n, N, device=dev)
+    if raw_noise_std and raw_noise_std > 0.:
+        B = float(density_scale)
+        for key, m in (("noise0", S),) + ((("noise1", S + N),) if N > 0 else ()):
+            if pytest:
+                np.random.seed(0); d[key] = f32(np.random.rand(n, m) * raw_noise_std)
+            else:
+                d[key] = torch.randn(n, m, device=dev) * (raw_noise_std * B)
+    if ray_noise_std and ray_noise_std > 0.:
+        d["ray_noise"] = torch.randn(n, S + N, 3, device=dev) * ray_noise_std
+    return d
 
 
 def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PREC_BF16, devices=None):

@@ -48,6 +48,15 @@ def weights_digest(w):
     return h.hexdigest()
 
 
+DRAW_KEYS = ("t_rand", "u_rand", "noise0", "noise1", "ray_noise")
+
+
+def golden_draws(g):
+    """The training-mode draws a rays_train* fixture holds (None for an eval fixture)."""
+    d = {k: torch.tensor(g[k]) for k in DRAW_KEYS if k in g}
+    return d or None
+
+
 def oracle_render_rays(g, cfg, extras=True):
     """Oracle on the inputs stored in a rays_* fixture."""
     wc, wf, tv, td = model_for(cfg, int(g["seed_model"]))
@@ -56,4 +65,5 @@ def oracle_render_rays(g, cfg, extras=True):
     cams = torch.tensor(g["cams"]) if "cams" in g else None
     return orc.render_rays(torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]),
                            torch.tensor(g["cyl"]), ocfg, torch_weights(wc), torch_weights(wf),
-                           cfg.n_samples, cfg.n_importance, cams=cams, return_extras=extras)
+                           cfg.n_samples, cfg.n_importance, cams=cams, return_extras=extras,
+                           draws=golden_draws(g))

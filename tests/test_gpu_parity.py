@@ -19,7 +19,7 @@ import torch
 
 from oracle import anerf_oracle as orc
 from posegen_amd import PREC_BF16, PREC_BF16X3, PREC_FP16, PREC_FP16C, PREC_FP16X3, PREC_FP32, PREC_NAMES
-from tests.helpers import (cfg_from_golden, load_golden, model_for, oracle_cfg, oracle_render_rays,
+from tests.helpers import (cfg_from_golden, golden_draws, load_golden, model_for, oracle_cfg, oracle_render_rays,
                            torch_weights)
 
 pytestmark = pytest.mark.gpu
@@ -246,6 +246,70 @@ def test_render_rays_vs_reference_golden(casters, name, prec):
     assert errs["alpha"] <= b_alpha
     assert set(out.keys()) == ({"rgb_map", "disp_map", "acc_map", "alpha"} |
                                ({"rgb0", "disp0", "acc0", "alpha0"} if cfg.n_importance > 0 else set()))
+
+
+@pytest.mark.parametrize("name", ["rays_train", "rays_train_coarse"])
+@pytest.mark.parametrize("prec", EXACT_MODES + FAST_MODES)
+def test_training_mode_forward_vs_reference_golden(casters, name, prec):
+    """render_kwargs_train call (perturb, raw_noise_std, ray_noise_std) against the reference's own
+    deterministic test mode, pytest=True (ray_utils.py:171-180, 241-244; nerf.py:179-182).  The
+    position noise has no pytest override in the reference: the fixture holds the two randn_like
+    results it drew, handed over as `draws` (rays_train); rays_train_coarse goes through
+    forward(pytest=True) itself, which must form the same numpy numbers."""
+    g = load_golden(name)
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), prec)
+    rb, skts, cyl, cams = _inputs(g)
+    n = rb.shape[0]
+    kw = dict(N_samples=cfg.n_samples, kp_batch=torch.tensor(g["kps"]).expand(n, -1, -1),
+              skts=skts.expand(n, -1, -1, -1), cyls=cyl.expand(n, -1), bones=torch.tensor(g["bones"]).expand(n, -1, -1),
+              cams=cams, N_importance=cfg.n_importance, perturb=float(g["perturb"]),
+              raw_noise_std=float(g["raw_noise_std"]), ray_noise_std=float(g["ray_noise_std"]), lindisp=False,
+              ext_scale=0.001, preproc_kwargs={}, nerf_type="nerf", use_viewdirs=True, pytest=True)
+    c.train()
+    try:
+        if "ray_noise" in g:
+            out = c(rb, draws=golden_draws(g), **kw)
+        else:
+            out = c(rb, **kw)
+    finally:
+        c.eval()
+    b_rgb, b_disp, b_alpha = BOUND[prec]
+    keys = ["rgb_map", "acc_map"] + (["rgb0", "acc0"] if cfg.n_importance > 0 else [])
+    errs = {k: _maxdiff(out[k].cpu().numpy(), g[k]) for k in keys}
+    errs["disp_map"] = _maxdiff(out["disp_map"].cpu().numpy(), g["disp_map"])
+    errs["alpha"] = float(np.quantile(np.abs(out["alpha"].cpu().numpy().astype(np.float64) - g["alpha"]), 0.99))
+    print(f"[{name} {PREC_NAMES[prec]} train] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    for k in keys:
+        assert errs[k] <= b_rgb, (k, errs[k])
+    assert errs["disp_map"] <= b_disp
+    assert errs["alpha"] <= b_alpha
+
+
+def test_training_mode_draws_change_the_image_and_eval_is_untouched(casters):
+    """Each draw is live (removing it moves the result), random draws differ call to call, and an
+    eval-mode call after training-mode calls is bitwise the eval result from before."""
+    g = load_golden("rays_train")
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), PREC_FP32)
+    rb, skts, cyl, cams = _inputs(g)
+    r = c.renderer
+    ev0 = r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance)
+    dr = golden_draws(g)
+    full = r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance, draws=dr)
+    for k in dr:
+        part = r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance,
+                             draws={kk: v for kk, v in dr.items() if kk != k})
+        assert _maxdiff(part["rgb_map"].cpu().numpy(), full["rgb_map"].cpu().numpy()) > 1e-5, k
+    a = c(rb, N_samples=cfg.n_samples, skts=skts, cyls=cyl, N_importance=cfg.n_importance, perturb=1., raw_noise_std=1.)
+    b = c(rb, N_samples=cfg.n_samples, skts=skts, cyls=cyl, N_importance=cfg.n_importance, perturb=1., raw_noise_std=1.)
+    assert _maxdiff(a["rgb_map"].cpu().numpy(), b["rgb_map"].cpu().numpy()) > 1e-4
+    ev1 = r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance)
+    for k in ("rgb_map", "acc_map", "disp_map", "alpha"):
+        assert torch.equal(ev0[k], ev1[k]), k
+    with pytest.raises(ValueError):
+        r.render_rays(rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance,
+                      draws={"t_rand": dr["t_rand"][:, :-1]})
 
 
 @pytest.mark.parametrize("name", ["rays_surreal", "rays_allhit", "rays_h36m"])

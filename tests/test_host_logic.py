@@ -265,3 +265,27 @@ def test_inline_asm_ring_reads_are_not_touched_by_the_compiler():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "AUDIT OK" in out.stdout
+
+
+def test_training_draws_follow_the_reference_places_and_test_mode():
+    """make_training_draws: which numbers exist for which switches, their shapes and scales, and
+    the pytest=True branch (numpy after seed 0, float64 -> float32, no B on the density noise:
+    ray_utils.py:171-180, 241-244; nerf.py:179-182) equal to the numbers stored in the fixture
+    made by the reference's own run."""
+    from posegen_amd.raycaster import make_training_draws
+    from tests.helpers import load_golden
+    g = load_golden("rays_train")
+    n, S, N = int(g["n_rays"]), int(g["n_samples"]), int(g["n_importance"])
+    d = make_training_draws(n, S, N, perturb=1., raw_noise_std=float(g["raw_noise_std"]), ray_noise_std=0., pytest=True,
+                            density_scale=7.0)
+    assert set(d) == {"t_rand", "u_rand", "noise0", "noise1"}
+    for k in d:
+        assert np.array_equal(d[k].numpy(), g[k]), k
+    assert make_training_draws(n, S, N) == {}
+    assert set(make_training_draws(n, S, 0, perturb=1., raw_noise_std=1.)) == {"t_rand", "noise0"}
+    torch.manual_seed(3)
+    r = make_training_draws(4096, 8, 4, perturb=1., raw_noise_std=2., ray_noise_std=0.5, density_scale=3.0)
+    assert r["t_rand"].shape == (4096, 8) and r["u_rand"].shape == (4096, 4) and r["ray_noise"].shape == (4096, 12, 3)
+    assert 0 <= float(r["t_rand"].min()) and float(r["t_rand"].max()) < 1
+    assert abs(float(r["noise0"].std()) - 6.0) < 0.15 and abs(float(r["noise1"].std()) - 6.0) < 0.15
+    assert abs(float(r["ray_noise"].std()) - 0.5) < 0.01

@@ -67,6 +67,25 @@ def test_render_rays_golden(name):
     np.testing.assert_allclose(out["alpha"].numpy(), g["alpha"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["rays_train", "rays_train_coarse"])
+def test_render_rays_training_mode_golden(name):
+    """Training-mode call of the reference in its own deterministic test mode (pytest=True:
+    numpy draws after seed 0; the position noise recorded as drawn): perturb, raw_noise_std,
+    ray_noise_std all on (rays_train) / jitter + density noise at N_importance = 0."""
+    g = load_golden(name)
+    cfg = cfg_from_golden(g)
+    out = oracle_render_rays(g, cfg)
+    assert float(g["perturb"]) > 0 and float(g["raw_noise_std"]) > 0
+    keys = ["rgb_map", "acc_map", "disp_map"] + (["rgb0", "acc0", "disp0"] if cfg.n_importance > 0 else [])
+    for k in keys:
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(out["alpha"].numpy(), g["alpha"], rtol=1e-3, atol=1e-4)
+    # the draws change the result: the same inputs in eval mode are a different image
+    g_eval = {k: v for k, v in g.items() if k not in ("t_rand", "u_rand", "noise0", "noise1", "ray_noise")}
+    ev = oracle_render_rays(g_eval, cfg)
+    assert np.abs(ev["rgb_map"].numpy() - g["rgb_map"]).max() > 1e-3
+
+
 def test_miss_rays_take_chunk_nanmean():
     """rays_surreal holds cylinder misses: their near/far equal the nanmean of the hits."""
     g = load_golden("rays_surreal")

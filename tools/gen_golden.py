@@ -284,6 +284,84 @@ def gen_render_rays(out, name, cfg, *, n_rays, H, all_hit, seed_model=0, seed_po
           f"mid-fraction={(np.logical_and(acc > 0.05, acc < 0.95)).mean():.2f}")
 
 
+def gen_render_rays_train(out, name, cfg, *, n_rays, H, seed_model=0, seed_pose=1, perturb=1.,
+                          raw_noise_std=1., ray_noise_std=0.005):
+    """Training-mode `RayCaster.__call__` (render_kwargs_train: perturb, raw_noise_std,
+    ray_noise_std) in the reference's own deterministic test mode, pytest=True: the stratified
+    jitter, the inverse-cdf positions and the density noise are numpy draws after
+    np.random.seed(0) (ray_utils.py:171-180, 241-244; nerf.py:179-182).  The position noise has
+    no such override (raycasters.py:660-661, 673-674): the two torch.randn_like results are
+    recorded as the reference makes them.  The fixture holds the draws (inputs) and the
+    outputs of the call."""
+    import torch
+    from core.utils.ray_utils import kp_to_valid_rays
+    from posegen_amd import synthetic as syn
+    with tempfile.TemporaryDirectory() as wd:
+        caster, kw, (wc, wf, tau_v, tau_d) = _build_reference_caster(cfg, seed_model, wd)
+    W = H
+    bones, kps, skts = syn.make_pose(1, seed_pose)
+    c2ws, focals = syn.make_camera(1, H, W)
+    rays, vids, cyls, boxes = kp_to_valid_rays(torch.tensor(c2ws), H, W, focals,
+                                               kps=torch.tensor(kps), ext_scale=cfg.ext_scale)
+    ro, rd = rays[0]
+    sel = np.unique(np.linspace(0, ro.shape[0] - 1, n_rays).round().astype(np.int64))
+    ro, rd = ro[sel].float(), rd[sel].float()
+    n = ro.shape[0]
+    vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    ones = torch.ones(n, 1)
+    batch = torch.cat([ro, rd, 0. * ones, 1. * ones, vd], -1)
+    kp_b = torch.tensor(kps).expand(n, -1, -1)
+    skt_b = torch.tensor(skts).expand(n, -1, -1, -1)
+    cyl_b = cyls.expand(n, -1)
+    bones_b = torch.tensor(bones).expand(n, -1, -1)
+    S, N = cfg.n_samples, cfg.n_importance
+    recorded = []
+    randn_like = torch.randn_like
+
+    def recording_randn_like(t, *a, **k):
+        r = randn_like(t, *a, **k)
+        recorded.append(r.clone())
+        return r
+
+    call_kw = {k: v for k, v in kw.items() if k != "ray_caster"}
+    call_kw.pop("use_viewdirs", None)
+    call_kw.update(perturb=perturb, raw_noise_std=raw_noise_std, ray_noise_std=ray_noise_std, pytest=True)
+    caster.train()
+    torch.manual_seed(1234)
+    torch.randn_like = recording_randn_like
+    try:
+        with torch.no_grad():
+            full = caster(batch, kp_batch=kp_b, skts=skt_b, cyls=cyl_b, bones=bones_b, cams=None,
+                          subject_idxs=None, **call_kw)
+    finally:
+        torch.randn_like = randn_like
+        caster.eval()
+    d = {"ray_batch": batch.numpy(), "kps": kps, "skts": skts, "bones": bones, "cyl": cyls.numpy(),
+         "tau_v": tau_v, "tau_d": tau_d, "seed_model": seed_model, "n_samples": S, "n_importance": N,
+         "framecode_ch": cfg.framecode_ch, "n_framecodes": cfg.n_framecodes,
+         "digest_coarse": _weights_digest(wc), "digest_fine": _weights_digest(wf),
+         "perturb": perturb, "raw_noise_std": raw_noise_std, "ray_noise_std": ray_noise_std, "n_rays": n}
+    # the pytest=True draws, exactly as the reference forms them (float64 numpy -> torch.Tensor = float32)
+    f32 = lambda a: torch.Tensor(a).numpy()
+    if perturb > 0:
+        np.random.seed(0); d["t_rand"] = f32(np.random.rand(n, S))
+        if N > 0:
+            np.random.seed(0); d["u_rand"] = f32(np.random.rand(n, N))
+    if raw_noise_std > 0:
+        np.random.seed(0); d["noise0"] = f32(np.random.rand(n, S) * raw_noise_std)
+        if N > 0:
+            np.random.seed(0); d["noise1"] = f32(np.random.rand(n, S + N) * raw_noise_std)
+    if ray_noise_std > 0:
+        assert len(recorded) == (2 if N > 0 else 1) and recorded[0].shape == (n, S, 3), [r.shape for r in recorded]
+        d["ray_noise"] = torch.cat([r * ray_noise_std for r in recorded], 1).numpy()
+    for k, v in full.items():
+        if torch.is_tensor(v):
+            d[k] = v.numpy()
+    np.savez_compressed(os.path.join(out, f"{name}.npz"), **d)
+    acc = full["acc_map"].numpy()
+    print(f"[{name}] rays={n} keys={sorted(k for k in full)} acc in [{acc.min():.3f},{acc.max():.3f}]")
+
+
 def gen_frame(out, name, cfg, H, chunk, seed_model=0, seed_pose=1, n_frames=2):
     """a-1/a-3: whole frames through the reference's render_path (bbox cull,
     chunk loop with a chunk boundary inside the frame, white background)."""
@@ -340,6 +418,11 @@ def main():
     if want("rays_cfg1"):        # BASELINE config 1: 32 coarse + 16 importance
         gen_render_rays(a.out, "rays_cfg1", surreal_config(n_samples=32, n_importance=16),
                         n_rays=96, H=128, all_hit=False, seed_pose=4)
+    if want("rays_train"):       # training-mode call: perturb + raw noise + ray noise, pytest=True draws
+        gen_render_rays_train(a.out, "rays_train", surreal_config(), n_rays=64, H=128, seed_pose=6)
+    if want("rays_train_coarse"):  # N_importance = 0, density noise and jitter only
+        gen_render_rays_train(a.out, "rays_train_coarse", surreal_config(n_samples=32, n_importance=0),
+                              n_rays=48, H=64, seed_pose=7, ray_noise_std=0.)
     if want("rays_h36m"):        # BASELINE config 4: frame codes, 128 coarse + 16
         gen_render_rays(a.out, "rays_h36m", h36m_config(), n_rays=64, H=128, all_hit=False,
                         seed_model=5, seed_pose=5, use_cams=True)
