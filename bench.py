@@ -36,7 +36,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0, "fp16c": 2500.0}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "fp16x3": 2500.0, "fp16c": 2500.0, "fp16m": 2500.0}
 METRIC = "rendered rays/sec (512x512, 64 samples/ray)"
 
 
@@ -339,7 +339,7 @@ def main():
 
     if world == 1 and not a.no_modes:
         modes = {}
-        for name in ("fp16c", "fp16", "bf16x3", "fp32"):
+        for name in ("fp16m", "fp16c", "fp16", "bf16x3", "fp32"):
             if name == a.prec or name not in PREC_BY_NAME:
                 continue
             r.set_precision(name)

@@ -45,7 +45,16 @@ extern "C" {
                              * 128 f16(W/129) * f16(x) + f16(W1 + 129 (W/129 - W1)) * f16(x1 + 129 (x - x1)):
                              * the cross terms W_lo x and W x_lo are recovered to 2^-7 of their size, so the
                              * operand rounding of plain fp16 drops ~30x (<= 1e-5 on rgb/acc) */
-#define PG_PREC_COUNT 6
+#define PG_PREC_COUNT 6     /* kernel arithmetics above; the modes below are plans over them */
+#define PG_PREC_FP16M 6     /* mixed: PG_PREC_FP16C for every pass whose maps are returned (the fine pass;
+                             * the coarse pass when N_importance == 0; density queries), plain PG_PREC_FP16
+                             * for the coarse pass of a hierarchical render, which only places the
+                             * importance samples.  NOT a 1e-4 mode: the fp16 error of the coarse weights
+                             * moves the importance samples, and the fine quadrature follows them --
+                             * measured rgb_map 7e-5, acc_map 1.1e-4 (fp16c 4e-6 / 8e-6, fp16 2.5e-4 /
+                             * 2.9e-4) at 1.37x fp16c's rate; bound asserted in the tests: 2e-4.
+                             * rgb0/disp0/acc0/alpha0 are plain fp16's. */
+#define PG_PREC_MODES 7
 
 /* flags of pg_render_rays */
 #define PG_FLAG_LINDISP 1   /* sample linearly in inverse depth (ray_utils.py:224-227) */
@@ -322,6 +331,13 @@ int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_t
 /* Compute units and maximum engine clock [kHz] of the handle's device (hipDeviceProp), for
  * re-deriving the MFMA peak on the box: n_cu x 4 SIMDs x 1024 bf16 FLOP/clk x clock. */
 int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz);
+
+/* Measurement aid (bench.py): the rate the handle's device SUSTAINS on bare
+ * v_mfma_f32_32x32x16_{bf16 (f16 = 0), f16 (f16 = 1)}: register operands with full mantissas, 2 waves
+ * per SIMD on every CU, nothing else in the loop, one launch of at least min_ms.  Synchronous.  The
+ * fused kernels are priced against the nominal 2.5 PFLOP/s; this is what the chip's clock management
+ * leaves of it under MFMA load on this box. */
+int pg_calibrate_mfma(pg_handle* h, int f16, double min_ms, double* tflops, double* ms);
 
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision (16-bit precisions:

@@ -7,8 +7,8 @@ library (`include/posegen_hip.h`).  There is no CPU fallback: every compute
 entry point raises if the HIP library is missing.
 """
 from .config import (RenderConfig, surreal_config, h36m_config, PREC_FP32, PREC_BF16,
-                     PREC_BF16X3, PREC_FP16, PREC_FP16X3, PREC_FP16C, PREC_NAMES, PREC_BY_NAME)
+                     PREC_BF16X3, PREC_FP16, PREC_FP16X3, PREC_FP16C, PREC_FP16M, PREC_NAMES, PREC_BY_NAME)
 
 __all__ = ["RenderConfig", "surreal_config", "h36m_config", "PREC_FP32", "PREC_BF16",
-           "PREC_BF16X3", "PREC_FP16", "PREC_FP16X3", "PREC_FP16C", "PREC_NAMES", "PREC_BY_NAME"]
+           "PREC_BF16X3", "PREC_FP16", "PREC_FP16X3", "PREC_FP16C", "PREC_FP16M", "PREC_NAMES", "PREC_BY_NAME"]
 __version__ = "0.1.0"

@@ -17,9 +17,12 @@ PREC_BF16X3 = 2   # split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate
 PREC_FP16 = 3     # fp16 operands, fp32 accumulate
 PREC_FP16X3 = 4   # split-fp16: hi*hi + hi*lo + lo*hi, fp32 accumulate
 PREC_FP16C = 5    # compensated fp16: 128 w1 x1 + w2 x2 (two products, one fp32 accumulator), ~30x below fp16's error
+PREC_FP16M = 6    # mixed: fp16c wherever a pass produces the returned maps, plain fp16 for the coarse pass of a
+                  # hierarchical render (it only places the importance samples).  NOT a 1e-4 mode: the samples
+                  # move with the coarse error (measured rgb 7e-5, acc 1.1e-4); bound 2e-4
 
 PREC_NAMES = {PREC_FP32: "fp32", PREC_BF16: "bf16", PREC_BF16X3: "bf16x3",
-              PREC_FP16: "fp16", PREC_FP16X3: "fp16x3", PREC_FP16C: "fp16c"}
+              PREC_FP16: "fp16", PREC_FP16X3: "fp16x3", PREC_FP16C: "fp16c", PREC_FP16M: "fp16m"}
 PREC_BY_NAME = {v: k for k, v in PREC_NAMES.items()}
 
 

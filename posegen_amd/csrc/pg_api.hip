@@ -30,6 +30,7 @@ int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
                             int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
+int pg_launch_mfma_rate(int f16, int blocks, int iters, float* sink, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
                         float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
                         float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
@@ -230,6 +231,14 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     return PG_OK;
 }
 
+// the packed weight streams a precision mode will use for net `which`, built ahead of the first render
+int ensure_mode_streams(pg_handle* h, int which, int mode) {
+    if (mode != PG_PREC_FP16M) return ensure_stream(h, which, mode, use_fact(mode, FACT_MIN_S));
+    int rc = ensure_stream(h, which, PG_PREC_FP16C, use_fact(PG_PREC_FP16C, FACT_MIN_S));
+    if (!rc && which == 0) rc = ensure_stream(h, which, PG_PREC_FP16, use_fact(PG_PREC_FP16, FACT_MIN_S));
+    return rc;
+}
+
 int ensure_ws(pg_handle* h, size_t bytes) {
     if (bytes <= h->ws_bytes) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
@@ -251,8 +260,10 @@ int check_ready(pg_handle* h, bool need_fine) {
 
 int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
                 const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
-                const float* points = nullptr, const float* pnoise = nullptr) {
-    const int prec = h->cfg.precision;
+                const float* points = nullptr, const float* pnoise = nullptr, bool guide_pass = false) {
+    // PG_PREC_FP16M: the coarse pass of a hierarchical render only places the importance samples (and fills
+    // rgb0/acc0): plain fp16 there, compensated fp16 wherever the pass produces the returned maps
+    const int prec = h->cfg.precision == PG_PREC_FP16M ? (guide_pass ? PG_PREC_FP16 : PG_PREC_FP16C) : h->cfg.precision;
     // explicit points and position noise need q = R p + t per point: the direct kernels (no per-ray a + z b table)
     const bool compk = !pnoise && use_comp_kernel(prec, S, points != nullptr);
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
@@ -330,7 +341,7 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
         return fail(nullptr, PG_EINVAL,
                     "pg_create: unsupported architecture (kernels are built for 24 joints, multires 7/4/0, "
                     "8x256 trunk, skip 4, view width 128, frame code 0|16)");
-    if (cfg->precision < 0 || cfg->precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
+    if (cfg->precision < 0 || cfg->precision >= PG_PREC_MODES) return fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
     if (is_x3(cfg->precision) && !x3_allowed())
         return fail(nullptr, PG_EINVAL, "pg_create: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", cfg->precision);
     if (cfg->chunk <= 0) return fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
@@ -432,7 +443,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
-    const int rc0 = ensure_stream(h, which, h->cfg.precision, use_fact(h->cfg.precision, FACT_MIN_S));
+    const int rc0 = ensure_mode_streams(h, which, h->cfg.precision);
     if (rc0) return rc0;
     PG_FORWARD(h, pg_load_weights(hh, which, tensors, shapes, n_tensors));
     return PG_OK;
@@ -474,12 +485,12 @@ int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) 
 
 int pg_set_precision(pg_handle* h, int precision) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_set_precision: null handle");
-    if (precision < 0 || precision >= PG_PREC_COUNT) return fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
+    if (precision < 0 || precision >= PG_PREC_MODES) return fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
     if (is_x3(precision) && !x3_allowed())
         return fail(h, PG_EINVAL, "pg_set_precision: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", precision);
     h->cfg.precision = precision;
     for (int w = 0; w < 2; ++w)
-        if (h->net[w].loaded) { int rc = ensure_stream(h, w, precision, use_fact(precision, FACT_MIN_S)); if (rc) return rc; }
+        if (h->net[w].loaded) { int rc = ensure_mode_streams(h, w, precision); if (rc) return rc; }
     PG_FORWARD(h, pg_set_precision(hh, precision));
     return PG_OK;
 }
@@ -571,9 +582,40 @@ int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz) {
     return PG_OK;
 }
 
+int pg_calibrate_mfma(pg_handle* h, int f16, double min_ms, double* tflops, double* ms_out) {
+    if (!h || !tflops) return fail(h, PG_EINVAL, "pg_calibrate_mfma: null argument");
+    PG_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 256);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    PG_HIP(h, hipEventCreate(&e0));
+    PG_HIP(h, hipEventCreate(&e1));
+    hipStream_t s = h->own_stream ? h->own_stream : nullptr;
+    int iters = 2000;                                   // ~1 ms per 1000 iterations of 32 MFMAs at 2 waves/SIMD
+    float ms = 0.0f;
+    int err = 0;
+    for (int round = 0; round < 6; ++round) {           // grow until one launch lasts min_ms: the clock settles in ms
+        (void)hipEventRecord(e0, s);
+        err = pg_launch_mfma_rate(f16, h->n_cu, iters, reinterpret_cast<float*>(h->ws), s);
+        (void)hipEventRecord(e1, s);
+        if (err || hipEventSynchronize(e1) != hipSuccess) break;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms >= min_ms && round > 0) break;
+        if (ms < min_ms) iters = (int)(iters * (ms > 0.05 ? 1.25 * min_ms / ms : 8.0)) + 1;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err) return fail(h, PG_EHIP, "calibration launch failed: %s", hipGetErrorString((hipError_t)err));
+    const double flop = (double)h->n_cu * 8.0 * (double)iters * 32.0 * 32768.0;
+    *tflops = flop / (ms * 1e-3) / 1e12;
+    if (ms_out) *ms_out = ms;
+    return PG_OK;
+}
+
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_query: null handle");
-    if (precision < 0 || precision >= PG_PREC_COUNT) return PG_EINVAL;
+    if (precision < 0 || precision >= PG_PREC_MODES) return PG_EINVAL;
+    if (precision == PG_PREC_FP16M) precision = PG_PREC_FP16C;      // the pass that produces the returned maps
     const bool fc = h->cfg.framecode_ch > 0;
     const bool sa = is_shape_a(precision);
     // 16-bit kernels: the factorised-view program (rays with >= 64 samples, the usual case)
@@ -718,7 +760,7 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
         int e0 = pg_launch_gather_noise(dr->ray_noise, n, SF, S, nullptr, pn, stream);
         if (e0) return fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e0));
     }
-    rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr, 0, nullptr, rnoise ? pn : nullptr);
+    rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr, 0, nullptr, rnoise ? pn : nullptr, hier);
     if (rc) return rc;
     int e = pg_launch_composite(ray_batch, zc, rawc, n, S, h->cfg.density_scale, h->cfg.rgb_eps,
                                 hier ? out->rgb0 : out->rgb_map, hier ? out->disp0 : out->disp_map,

@@ -564,6 +564,73 @@ extern "C" int pg_launch_composite(const float* rays, const float* z, const floa
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// MFMA calibration: the rate this device SUSTAINS on v_mfma_f32_32x32x16_{bf16,f16} with nothing else
+// in the loop (operands in registers, non-trivial values: the clock the chip holds under MFMA load
+// depends on the data).  bench.py reports it beside the nominal peak: the fused kernels are priced
+// against the nominal figure, this says how much of the gap is the chip's own clock management.
+// 8 waves per workgroup (2 per SIMD), one workgroup per CU, 4 independent accumulator chains.
+// ------------------------------------------------------------------------------------
+namespace pgk {
+typedef _Float16 cal_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cal_b8 __attribute__((ext_vector_type(8)));
+typedef float cal_f16v __attribute__((ext_vector_type(16)));
+
+template <bool F16>
+__global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    // operand values in (-1, 1) with full mantissas, different per lane and element
+    float seed = 0.37f + 0.0131f * (float)lane + 0.00071f * (float)(threadIdx.x >> 6);
+    cal_f16v acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.0f;
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        seed = seed * 1.6180339f; seed -= floorf(seed);
+        av[e] = seed - 0.5f;
+        seed = seed * 2.2360679f; seed -= floorf(seed);
+        bv[e] = (seed - 0.5f) * 0.25f;
+    }
+    if constexpr (F16) {
+        cal_h8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = (_Float16)av[e]; b[e] = (_Float16)bv[e]; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+        }
+    } else {
+        cal_b8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = (__bf16)av[e]; b[e] = (__bf16)bv[e]; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+        }
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[c][e];
+    if (r == 123.456f) sink[0] = r;        // never true for these operands; keeps the chains alive
+}
+}  // namespace pgk
+
+// launches `blocks` workgroups x 8 waves x iters x 32 MFMAs; returns 0 or the hipError
+extern "C" int pg_launch_mfma_rate(int f16, int blocks, int iters, float* sink, void* stream) {
+    if (f16) hipLaunchKernelGGL(pgk::mfma_rate_kernel<true>, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), iters, sink);
+    else hipLaunchKernelGGL(pgk::mfma_rate_kernel<false>, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), iters, sink);
+    return (int)hipGetLastError();
+}
+
 extern "C" int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream) {
     if (n <= 0) return 0;
     const long long tot = n * S;

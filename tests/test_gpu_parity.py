@@ -18,7 +18,8 @@ import pytest
 import torch
 
 from oracle import anerf_oracle as orc
-from posegen_amd import PREC_BF16, PREC_BF16X3, PREC_FP16, PREC_FP16C, PREC_FP16X3, PREC_FP32, PREC_NAMES
+from posegen_amd import (PREC_BF16, PREC_BF16X3, PREC_FP16, PREC_FP16C, PREC_FP16M, PREC_FP16X3, PREC_FP32,
+                         PREC_NAMES)
 from tests.helpers import (cfg_from_golden, golden_draws, load_golden, model_for, oracle_cfg, oracle_render_rays,
                            torch_weights)
 
@@ -246,6 +247,39 @@ def test_render_rays_vs_reference_golden(casters, name, prec):
     assert errs["alpha"] <= b_alpha
     assert set(out.keys()) == ({"rgb_map", "disp_map", "acc_map", "alpha"} |
                                ({"rgb0", "disp0", "acc0", "alpha0"} if cfg.n_importance > 0 else set()))
+
+
+@pytest.mark.parametrize("name", RAY_CASES)
+def test_mixed_mode_bounds_and_pass_selection(casters, name):
+    """PG_PREC_FP16M: plain fp16 for the coarse pass of a hierarchical render (it only places the
+    importance samples), compensated fp16 for the pass that produces the returned maps.  It is not a
+    1e-4 mode (the fine quadrature follows the importance samples, which move with the coarse
+    weights' fp16 error): against the reference's vectors rgb_map / acc_map / disp_map <= 2e-4;
+    rgb0 / acc0 are the fp16 kernel's, bitwise; with N_importance = 0 the only pass is the final
+    one, so the result equals fp16c bitwise."""
+    g = load_golden(name)
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), PREC_FP16M)
+    rb, skts, cyl, cams = _inputs(g)
+    kw = dict(cams=cams, n_samples=cfg.n_samples, n_importance=cfg.n_importance)
+    out = c.renderer.render_rays(rb, skts, cyl, **kw)
+    errs = {k: _maxdiff(out[k].cpu().numpy(), g[k]) for k in ("rgb_map", "acc_map", "disp_map")}
+    if cfg.n_importance > 0:
+        errs.update({k: _maxdiff(out[k].cpu().numpy(), g[k]) for k in ("rgb0", "acc0")})
+    print(f"[{name} fp16m] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    for k in ("rgb_map", "acc_map", "disp_map"):
+        assert errs[k] <= 2e-4, (k, errs[k])
+    c.renderer.set_precision(PREC_FP16C)
+    ref_c = c.renderer.render_rays(rb, skts, cyl, **kw)
+    if cfg.n_importance > 0:
+        assert errs["rgb0"] <= BOUND[PREC_FP16][0] and errs["acc0"] <= BOUND[PREC_FP16][0]
+        c.renderer.set_precision(PREC_FP16)
+        ref_h = c.renderer.render_rays(rb, skts, cyl, **kw)
+        for k in ("rgb0", "acc0", "disp0", "alpha0"):      # the coarse pass IS the fp16 kernel
+            assert torch.equal(out[k], ref_h[k]), k
+    else:
+        for k in ("rgb_map", "acc_map", "disp_map", "alpha"):
+            assert torch.equal(out[k], ref_c[k]), k
 
 
 @pytest.mark.parametrize("name", ["rays_train", "rays_train_coarse"])

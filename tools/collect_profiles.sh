@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profiles on the GPU box: kernel stats + separate PMC passes of the default bench workload.
+# usage: tools/collect_profiles.sh <tag> [bench args...]   (writes gpurun_out/prof_<tag>/)
+set -e -o pipefail
+tag=$1; shift
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes --no-extras $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $B > $out/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $out/mfma -- $B > $out/mfma.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $out/sq -- $B > $out/sq.log 2>&1
+find $out -name "*.csv" | head -40
