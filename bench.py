@@ -311,16 +311,27 @@ def main():
     result["roofline"]["executed_tflops"] = k_tflops * ex / flops_pt
     result["roofline"]["executed_frac"] = k_tflops * ex / flops_pt / peak
 
+    # What this box SUSTAINS on bare 32x32x16 MFMAs (register operands, 2 waves per SIMD on every CU,
+    # nothing else in the loop, one >= 20 ms launch): `peak` stays the nominal dense figure, this says how
+    # much of the gap is the chip's clock management under MFMA load rather than the kernel's stalls.
+    if a.prec != "fp32" and world == 1:
+        cal = r.calibrate_mfma(f16=a.prec != "bf16")
+        result["roofline"]["sustained_mfma_tflops"] = cal["tflops"]
+        result["roofline"]["sustained_mfma_from"] = (f"bare v_mfma_f32_32x32x16_{'bf16' if a.prec == 'bf16' else 'f16'} loop, "
+                                                     f"{cal['ms']:.1f} ms launch on this box (pg_calibrate_mfma)")
+        result["roofline"]["executed_frac_of_sustained"] = result["roofline"]["executed_tflops"] / cal["tflops"]
+
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the
     # profiler on itself, so the committed measurement of the same build is attached.
-    for tname in ("r2_traffic.json", "r1_traffic.json"):
+    alg_bytes = 20 * k_pts / max(launches, 1)       # z in 4 B/point + raw out 16 B/point
+    for tname in (f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
-        if a.prec == "bf16" and H == 512 and os.path.exists(tpath):
+        if H == 512 and os.path.exists(tpath) and (a.prec == "bf16" or tname.startswith("r2_")):
             tj = json.load(open(tpath))
             result["roofline"]["traffic"] = tj["hbm_bytes"]
             result["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{tname})"
-            result["roofline"]["algorithmic_bytes_per_launch"] = tj["algorithmic_bytes"]
+            result["roofline"]["algorithmic_bytes_per_launch"] = tj.get("algorithmic_bytes", alg_bytes)
             break
 
     sel = ref = None
