@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import anerf_oracle as orc
+from posegen_amd import PREC_FP16C
 from posegen_amd import _ffi, synthetic as syn
 from posegen_amd.config import PREC_BF16, PREC_FP16, PREC_FP32, RenderConfig, h36m_config, surreal_config
 from posegen_amd.raycaster import NET_TENSOR_ORDER
@@ -63,7 +64,7 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
-    if fact:
+    if fact and prec != PREC_FP16C:      # the compensated kernel has no Y stage (direct view layer)
         n = C.c_int64()
         rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(n))
         assert rc == 0, lib.pg_last_error(None)
@@ -239,6 +240,103 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
     gv, _ = hidden_vals(vt)
     rgb = segment(1, km, [(gv, VW // 2)], BT_RGB)[0]
     return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
+
+
+def emulate_c(stream, bias, chunk_bytes, x, cfg):
+    """The compensated-fp16 program (pg_program.h C, pg_evalc.hip): every segment k-major, every
+    (input unit, out tile) a PAIR of 1-KiB units -- plane 0 = (S-1) f16(W/S) against x1 = f16(x),
+    plane 1 = f16(w1 + S (W/S - w1)) against x2 = f16(x1 + S (x - x1)) -- into one accumulator."""
+    S = 129.0
+    wv = Wave(stream, chunk_bytes, PREC_FP16)          # both planes are fp16 fragments
+
+    def h16(v):
+        return v.astype(np.float16).astype(np.float32)
+
+    def pair_vals(fn, n, src):
+        v = np.zeros((2, n, 32), dtype=np.float32)
+        for h in range(2):
+            for i in range(n):
+                ch = fn(i, h)
+                if ch >= 0:
+                    v[h, i] = src[:, ch]
+        x1 = h16(v)
+        x2 = h16(x1 + np.float32(S) * (v - x1))
+        return x1, x2
+
+    def bias_tile(t):
+        b = bias[t * 32:(t + 1) * 32].reshape(2, 16)
+        out = np.zeros((32, 1), dtype=np.float32)
+        for h in range(2):
+            for r in range(16):
+                out[rho(r, h), 0] = b[h, r]
+        return np.repeat(out, 32, axis=1)
+
+    def segment(no, inputs, acc):
+        wv_units = [(p1, p2, u) for (p1, p2), n in inputs for u in range(n // 8)]
+        for P in range(len(wv_units) * no):
+            ui, o = P // no, P % no
+            p1, p2, u = wv_units[ui]
+            wv.mma(acc, 2 * P, o, p1, u)
+            wv.mma(acc, 2 * P + 1, o, p2, u)
+        return acc
+
+    def hidden(tiles, relu=True):
+        act = np.concatenate(tiles, 0)
+        if relu:
+            act = np.maximum(act, 0)
+        return pair_vals(hseq_channel, len(tiles) * 16, act.T)
+
+    tiles_of = lambda t0, n: [bias_tile(t0 + o) for o in range(n)]
+    xs = pair_vals(xseq_channel, XSEQ, x[:, :432])
+    tiles = segment(NT, [(xs, XSEQ)], tiles_of(0, NT))
+    for l in range(1, 5):
+        tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
+    tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(5 * NT, NT))
+    tiles = segment(NT, [(xs, XSEQ)], tiles)
+    for l in (6, 7):
+        tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
+    av = segment(NTV + 1, [(hidden(tiles), HSEQ)], [bias_tile(BT_ALPHA)] + tiles_of(BT_VIEWF, NTV))
+    sigma = av[0][0]
+    ins = [(pair_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
+    if cfg.framecode_ch:
+        ins.append((pair_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
+    vt = segment(NTV, ins, av[1:])
+    rgb = segment(1, [(hidden(vt), VW // 2)], [bias_tile(BT_RGB)])[0]
+    return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
+
+
+@pytest.mark.parametrize("fc", [False, True])
+def test_packed_compensated_stream_reproduces_mlp(fc):
+    """The fp16c stream as the kernel consumes it (pairs of planes, k-major, every segment on a chunk
+    boundary) against the fp32 oracle: the compensation itself is what is tested -- plain fp16 is at
+    4e-3 on this input (test below), the pair must be 40x closer."""
+    try:
+        _ffi.load_library()
+    except _ffi.HipLibraryError as e:
+        pytest.skip(str(e))
+    cfg = h36m_config() if fc else surreal_config()
+    w = syn.make_weights(cfg, 3)
+    stream, bias, chunk_bytes, _ = pack(w, cfg, PREC_FP16C, True)
+    rng = np.random.RandomState(0)
+    x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
+    x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)
+    ocfg = oracle_cfg(cfg, 79.6, 79.6)
+    tw = {k: torch.tensor(v) for k, v in w.items()}
+    if fc:
+        idx = rng.randint(0, cfg.n_framecodes, size=(32, 1)).astype(np.float32)
+        ref = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1)), tw, ocfg).numpy()
+        x_em = np.concatenate([x, w["framecodes.codes.weight"][idx[:, 0].astype(int)]], 1)
+    else:
+        ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
+        x_em = x
+    raw, n_chunks = emulate_c(stream, bias, chunk_bytes, x_em, cfg)
+    assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
+    err = float(np.abs(raw - ref).max())
+    print(f"fp16c stream emulation vs fp32 oracle: {err:.2e} (|ref| max {np.abs(ref).max():.2f})")
+    assert err <= 1e-4 * max(1.0, float(np.abs(ref).max()) / 10)
+    ocfg.quant = "fp16c"
+    emu = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1) if fc else x), tw, ocfg).numpy()
+    assert float(np.abs(raw - emu).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()) / 10)
 
 
 @pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 2e-2), (PREC_FP16, "fp16", 4e-3)])
