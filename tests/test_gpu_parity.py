@@ -374,6 +374,43 @@ def test_render_rays_fast_modes(casters, name, prec, quant):
     assert e_disp <= b_disp
 
 
+@pytest.mark.parametrize("S,N,lindisp", [(64, 16, True), (192, 64, False), (256, 0, False), (32, 2, False), (240, 16, True)])
+def test_lindisp_and_maximum_sample_counts(casters, S, N, lindisp):
+    """Sampling in inverse depth (ray_utils.py:224-227) and the limits of the kernels: N_samples up to 256,
+    N_importance up to 64, N_samples + N_importance = 256, the smallest importance count (2)."""
+    g = load_golden("rays_allhit")
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), PREC_FP32)
+    rb, skts, cyl, cams = _inputs(g)
+    rb = rb[::2][:48]
+    out = c.renderer.render_rays(rb, skts, cyl, n_samples=S, n_importance=N, lindisp=lindisp, extras=True)
+    wc, wf, tv, td = model_for(cfg, int(g["seed_model"]))
+    ocfg = oracle_cfg(cfg, g["tau_v"], g["tau_d"])
+    ref = orc.render_rays(rb, skts, cyl, ocfg, torch_weights(wc), torch_weights(wf), S, N, lindisp=lindisp,
+                          return_extras=True)
+    np.testing.assert_allclose(out["extras"]["z_coarse"].cpu().numpy(), ref["extras"]["z_coarse"].numpy(), rtol=2e-6, atol=1e-7)
+    errs = {k: _maxdiff(out[k].cpu().numpy(), ref[k].numpy()) for k in ("rgb_map", "acc_map")}
+    solid = ref["acc_map"].numpy() > 1e-3
+    errs["disp_map"] = _maxdiff(out["disp_map"].cpu().numpy()[solid], ref["disp_map"].numpy()[solid]) if solid.any() else 0.0
+    print(f"[S={S} N={N} lindisp={lindisp}] " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) <= 1e-4
+    assert float(ref["acc_map"].max()) > 0.5, "the case must contain rays that hit the body"
+    assert out["alpha"].shape == (48, S + N)
+
+
+def test_sample_counts_beyond_the_kernel_limits_are_refused(casters):
+    from posegen_amd._ffi import PgError
+    g = load_golden("rays_surreal")
+    cfg = cfg_from_golden(g)
+    c = casters(cfg, int(g["seed_model"]), PREC_FP32)
+    rb, skts, cyl, cams = _inputs(g)
+    for S, N in ((257, 0), (64, 65), (250, 16), (64, 1), (1, 0)):
+        with pytest.raises(PgError):
+            c.renderer.render_rays(rb[:8], skts, cyl, n_samples=S, n_importance=N)
+    ok = c.renderer.render_rays(rb[:8], skts, cyl, n_samples=64, n_importance=16)     # the handle survives the refusals
+    assert torch.isfinite(ok["rgb_map"]).all()
+
+
 def test_render_rays_chunk_boundary_and_ragged_sizes(casters):
     """n not a multiple of the 256-point pass, several nanmean groups, n = 1."""
     g = load_golden("rays_surreal")
