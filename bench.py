@@ -320,6 +320,11 @@ def main():
         result["roofline"]["sustained_mfma_from"] = (f"bare v_mfma_f32_32x32x16_{'bf16' if a.prec == 'bf16' else 'f16'} loop, "
                                                      f"{cal['ms']:.1f} ms launch on this box (pg_calibrate_mfma)")
         result["roofline"]["executed_frac_of_sustained"] = result["roofline"]["executed_tflops"] / cal["tflops"]
+        # the same loop with the A operand of every MFMA read from LDS (one ds_read_b128 per MFMA and wave):
+        # the ceiling of the kernels' structure -- 32 points per wave, weight fragments from the LDS ring
+        cal2 = r.calibrate_mfma(f16=a.prec != "bf16", lds_fed=True)
+        result["roofline"]["sustained_mfma_lds_fed_tflops"] = cal2["tflops"]
+        result["roofline"]["executed_frac_of_lds_fed"] = result["roofline"]["executed_tflops"] / cal2["tflops"]
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the

@@ -336,8 +336,10 @@ int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz);
  * v_mfma_f32_32x32x16_{bf16 (f16 = 0), f16 (f16 = 1)}: register operands with full mantissas, 2 waves
  * per SIMD on every CU, nothing else in the loop, one launch of at least min_ms.  Synchronous.  The
  * fused kernels are priced against the nominal 2.5 PFLOP/s; this is what the chip's clock management
- * leaves of it under MFMA load on this box. */
-int pg_calibrate_mfma(pg_handle* h, int f16, double min_ms, double* tflops, double* ms);
+ * leaves of it under MFMA load on this box.  lds_fed = 1: the A operand of every MFMA is read from LDS
+ * (one conflict-free ds_read_b128 per MFMA and wave, like the weight ring): the ceiling of the fused
+ * 16-bit kernels' structure (32 points per wave, weights from LDS). */
+int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double* tflops, double* ms);
 
 /* Static facts for the host: bytes of the packed weight stream of one net, and the
  * MFMA instructions one 32-point group issues, for the given precision (16-bit precisions:

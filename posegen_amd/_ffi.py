@@ -66,7 +66,7 @@ PROTOTYPES = {
     "pg_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
                                  C.c_int, C.c_int, C.c_int, C.POINTER(PgOutputs)]),
-    "pg_calibrate_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pg_calibrate_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pg_render_rays_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
                                        C.c_int, C.c_int, C.c_int, C.POINTER(PgTrainDraws), C.POINTER(PgOutputs)]),
     "pg_stage_sample_coarse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, C.c_int,

@@ -30,7 +30,7 @@ int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
                             int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
-int pg_launch_mfma_rate(int f16, int blocks, int iters, float* sink, void* stream);
+int pg_launch_mfma_rate(int f16, int lds_fed, int blocks, int iters, float* sink, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
                         float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
                         float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
@@ -582,7 +582,7 @@ int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz) {
     return PG_OK;
 }
 
-int pg_calibrate_mfma(pg_handle* h, int f16, double min_ms, double* tflops, double* ms_out) {
+int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double* tflops, double* ms_out) {
     if (!h || !tflops) return fail(h, PG_EINVAL, "pg_calibrate_mfma: null argument");
     PG_HIP(h, hipSetDevice(h->device));
     int rc = ensure_ws(h, 256);
@@ -596,7 +596,7 @@ int pg_calibrate_mfma(pg_handle* h, int f16, double min_ms, double* tflops, doub
     int err = 0;
     for (int round = 0; round < 6; ++round) {           // grow until one launch lasts min_ms: the clock settles in ms
         (void)hipEventRecord(e0, s);
-        err = pg_launch_mfma_rate(f16, h->n_cu, iters, reinterpret_cast<float*>(h->ws), s);
+        err = pg_launch_mfma_rate(f16, lds_fed, h->n_cu, iters, reinterpret_cast<float*>(h->ws), s);
         (void)hipEventRecord(e1, s);
         if (err || hipEventSynchronize(e1) != hipSuccess) break;
         (void)hipEventElapsedTime(&ms, e0, e1);

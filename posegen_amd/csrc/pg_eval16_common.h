@@ -167,10 +167,20 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
 #ifndef PG_SETPRIO
 #define PG_SETPRIO 0
 #endif
+// PG_ALT_PRIO (experiment): the two waves of a SIMD (w and w + NWAVE/2) take turns at raised issue priority,
+// switching every out tile / unit row, so that both reach a chunk barrier together instead of the older one
+// winning every arbitration and then waiting there (stamps: waves 0-3 spend 27 % of a pass in s_barrier).
+__device__ __forceinline__ void alt_prio(int wave, int phase) {
+#if defined(PG_ALT_PRIO)
+    const bool hi = (((phase / PG_ALT_PRIO) & 1) != 0) == (wave >= 4);      // wave-uniform
+    if (hi) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 // one B fragment against NO out tiles; unit row uu of a k-major segment with T units
 template <typename V, int NO, int T, bool ASYNC, int NS, typename ST>
 __device__ __forceinline__ void mma_row(f32x16* acc, APipe<V, NS>& p, ST& st, int uu, V b) {
     if (PG_SETPRIO) __builtin_amdgcn_s_setprio(PG_SETPRIO);
+    alt_prio(st.wave, uu);
 #pragma unroll
     for (int o = 0; o < NO; ++o) acc[o] = Op<V>::mfma(next_a<V, T, ASYNC, NS>(p, st, uu * NO + o), b, acc[o]);
     if (PG_SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -265,6 +275,7 @@ __device__ __forceinline__ void hidden_layer(const V* fin, V* fout, ST& st, int 
     for (int o = 0; o < NT; ++o) {
         f32x16 acc = nextb;
         constexpr int T = HU * NT;
+        alt_prio(st.wave, o);
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             acc = Op<V>::mfma(next_a<V, T, true, PG_PIPE_H>(p, st, o * HU + u), fin[u], acc);

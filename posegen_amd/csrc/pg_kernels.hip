@@ -576,8 +576,13 @@ typedef _Float16 cal_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cal_b8 __attribute__((ext_vector_type(8)));
 typedef float cal_f16v __attribute__((ext_vector_type(16)));
 
-template <bool F16>
+// LDSFED: the A operand of every MFMA comes from LDS (one conflict-free ds_read_b128 per MFMA and wave, a
+// lane-linear 1-KiB fragment image like the weight ring's), reads issued one MFMA ahead: the structural
+// ceiling of "32 points per wave, weights from LDS" -- what the fused 16-bit kernels could reach if the
+// fragment reads were their only cost.
+template <bool F16, bool LDSFED>
 __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) unsigned frag[32 * 256];      // 32 fragments of 1 KiB
     const int lane = threadIdx.x & 63;
     // operand values in (-1, 1) with full mantissas, different per lane and element
     float seed = 0.37f + 0.0131f * (float)lane + 0.00071f * (float)(threadIdx.x >> 6);
@@ -594,25 +599,40 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __rest
         seed = seed * 2.2360679f; seed -= floorf(seed);
         bv[e] = (seed - 0.5f) * 0.25f;
     }
+    typedef unsigned cal_u4 __attribute__((ext_vector_type(4)));
+    cal_u4 a, b;
     if constexpr (F16) {
-        cal_h8 a, b;
+        cal_h8 ah, bh;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = (_Float16)av[e]; b[e] = (_Float16)bv[e]; }
+        for (int e = 0; e < 8; ++e) { ah[e] = (_Float16)av[e]; bh[e] = (_Float16)bv[e]; }
+        a = __builtin_bit_cast(cal_u4, ah); b = __builtin_bit_cast(cal_u4, bh);
+    } else {
+        cal_b8 ab, bb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ab[e] = (__bf16)av[e]; bb[e] = (__bf16)bv[e]; }
+        a = __builtin_bit_cast(cal_u4, ab); b = __builtin_bit_cast(cal_u4, bb);
+    }
+    auto mma = [&](cal_f16v& c, const cal_u4& x) {
+        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cal_h8, x), __builtin_bit_cast(cal_h8, b), c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cal_b8, x), __builtin_bit_cast(cal_b8, b), c, 0, 0, 0);
+    };
+    if constexpr (LDSFED) {
+        for (int i = threadIdx.x; i < 32 * 256; i += 512) frag[i] = a[i & 3] ^ (unsigned)(i >> 8) * 0x00010001u;
+        __syncthreads();
+        const cal_u4* img = reinterpret_cast<const cal_u4*>(frag) + lane;      // fragment f: img[f * 64]
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+            for (int u = 0; u < 32; ++u) {
+                const cal_u4 x = img[u * 64];
+                mma(acc[u & 3], x);
+            }
         }
     } else {
-        cal_b8 a, b;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = (__bf16)av[e]; b[e] = (__bf16)bv[e]; }
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) mma(acc[c], a);
         }
     }
     float r = 0.0f;
@@ -625,9 +645,12 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __rest
 }  // namespace pgk
 
 // launches `blocks` workgroups x 8 waves x iters x 32 MFMAs; returns 0 or the hipError
-extern "C" int pg_launch_mfma_rate(int f16, int blocks, int iters, float* sink, void* stream) {
-    if (f16) hipLaunchKernelGGL(pgk::mfma_rate_kernel<true>, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), iters, sink);
-    else hipLaunchKernelGGL(pgk::mfma_rate_kernel<false>, dim3(blocks), dim3(512), 0, static_cast<hipStream_t>(stream), iters, sink);
+extern "C" int pg_launch_mfma_rate(int f16, int lds_fed, int blocks, int iters, float* sink, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f16 && lds_fed) hipLaunchKernelGGL((pgk::mfma_rate_kernel<true, true>), dim3(blocks), dim3(512), 0, s, iters, sink);
+    else if (f16) hipLaunchKernelGGL((pgk::mfma_rate_kernel<true, false>), dim3(blocks), dim3(512), 0, s, iters, sink);
+    else if (lds_fed) hipLaunchKernelGGL((pgk::mfma_rate_kernel<false, true>), dim3(blocks), dim3(512), 0, s, iters, sink);
+    else hipLaunchKernelGGL((pgk::mfma_rate_kernel<false, false>), dim3(blocks), dim3(512), 0, s, iters, sink);
     return (int)hipGetLastError();
 }
 

@@ -143,10 +143,12 @@ class HipRenderer:
         self._check(self.lib.pg_device_info(self.handle, C.byref(n), C.byref(k)))
         return {"n_cu": n.value, "clock_khz": k.value}
 
-    def calibrate_mfma(self, f16=False, min_ms=20.0):
-        """TFLOP/s this device sustains on bare 32x32x16 MFMAs (pg_calibrate_mfma); synchronous."""
+    def calibrate_mfma(self, f16=False, lds_fed=False, min_ms=20.0):
+        """TFLOP/s this device sustains on bare 32x32x16 MFMAs, operands in registers or (lds_fed) the A
+        operand read from LDS per MFMA (pg_calibrate_mfma); synchronous."""
         tf, ms = C.c_double(), C.c_double()
-        self._check(self.lib.pg_calibrate_mfma(self.handle, 1 if f16 else 0, float(min_ms), C.byref(tf), C.byref(ms)))
+        self._check(self.lib.pg_calibrate_mfma(self.handle, 1 if f16 else 0, 1 if lds_fed else 0, float(min_ms),
+                                               C.byref(tf), C.byref(ms)))
         return {"tflops": tf.value, "ms": ms.value}
 
     def query(self, precision=None):
