@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .rays import kp_to_boxes, kp_to_valid_rays
+from .rays import get_rays, kp_to_boxes, kp_to_valid_rays
 
 
 def _caster_device(ray_caster):
@@ -40,11 +40,19 @@ def batchify_rays(rays_flat, chunk=1024 * 32, ray_caster=None, **kwargs):
 def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, near=0., far=1., center=None,
            use_viewdirs=False, c2w_staticcam=None, **kwargs):
     """Pack `ray_batch = [o, d, near, far, viewdir]` and render it (trainer.py:84-147)."""
-    if rays is None:
-        raise NotImplementedError("render(): pass rays=(rays_o, rays_d); full-frame c2w rendering goes "
-                                  "through render_path")
     r, dev = _caster_device(kwargs["ray_caster"])
-    rays_o, rays_d = rays
+    if rays is None:
+        if c2w is None:
+            raise ValueError("render(): pass rays=(rays_o, rays_d) or a camera c2w")
+        # the full-image special case (trainer.py:109-113): every pixel of the H x W frame
+        center = None if center is None else np.asarray(center).ravel()
+        rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w, dtype=torch.float32), center=center)
+    else:
+        rays_o, rays_d = rays
+    if c2w_staticcam is not None:
+        # trainer.py:122-124: directions of `c2w` feed the (numerically dead, SURVEY a-5) viewdir columns,
+        # the rays themselves come from the static camera
+        rays_o, rays_d = get_rays(H, W, focal, torch.as_tensor(c2w_staticcam, dtype=torch.float32))
     sh = rays_d.shape
     rays_o = torch.reshape(rays_o, [-1, 3]).float().to(dev)
     rays_d = torch.reshape(rays_d, [-1, 3]).float().to(dev)

@@ -89,6 +89,70 @@ def test_rays_are_independent_of_batching(caster):
         assert torch.equal(full[k][5000:5777], part[k])
 
 
+def test_render_full_image_from_a_camera_equals_explicit_rays(caster):
+    """render(H, W, focal, c2w=...) without rays: the reference's full-image special case
+    (trainer.py:109-113) = get_rays of every pixel, result reshaped to [H, W, ...]."""
+    from posegen_amd.rays import get_rays
+    from posegen_amd.render import render
+    g = load_golden("frame64")
+    cfg = caster.cfg
+    H, W = int(g["H"]), int(g["W"])
+    c2w, focal = torch.tensor(g["c2ws"][0]), float(g["focals"][0])
+    from posegen_amd.skeleton import get_kp_bounding_cylinder
+    cyl = torch.tensor(np.asarray(get_kp_bounding_cylinder(g["kps"][:1], ext_scale=cfg.ext_scale, extend_mm=250,
+                                                           top_expand_ratio=1.60, bot_expand_ratio=1.10, head="-y")),
+                       dtype=torch.float32)
+    kw = dict(ray_caster=caster, N_samples=cfg.n_samples, N_importance=cfg.n_importance, skts=torch.tensor(g["skts"][:1]),
+              cyls=cyl, kp_batch=None)
+    caster.renderer.set_precision(PREC_FP32)
+    a = render(H, W, focal, chunk=4096, c2w=c2w[:3, :4], **kw)
+    ro, rd = get_rays(H, W, focal, c2w[:3, :4])
+    b = render(H, W, focal, chunk=4096, rays=(ro, rd), **kw)
+    assert a["rgb_map"].shape == (H, W, 3) and a["acc_map"].shape == (H, W)
+    for k in ("rgb_map", "disp_map", "acc_map"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["acc_map"].max()) > 0.5
+    with pytest.raises(ValueError):
+        render(H, W, focal, chunk=4096, **kw)
+
+
+def test_multi_subject_batch_keeps_every_subjects_caster_resident(tmp_path):
+    """BASELINE config 4's "multi-subject batch": several subjects = several checkpoints, rendered in one
+    batch of frames.  Each subject's caster stays loaded (load_raycaster memoises per file); frames rendered
+    interleaved across subjects are bitwise the frames of each subject rendered alone."""
+    from posegen_amd.config import h36m_config
+    from posegen_amd.raycaster import HipRayCaster, load_raycaster
+    from posegen_amd.render import render_path
+    cfg = h36m_config()
+    H = W = 64
+    paths = []
+    for s_ in range(3):
+        c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 10 + s_), device=DEV, precision=PREC_BF16)
+        p = str(tmp_path / f"subject{s_}.tar")
+        torch.save(c.state_dict(), p)
+        c.renderer.close()
+        paths.append(p)
+    _, kps, skts = syn.make_pose(4, 3)
+    c2ws, focals = syn.make_camera(4, H, W)
+    cams = torch.tensor([0., 1., 2., 3.])
+
+    def frames(path, ids):
+        kw = load_raycaster(path, cfg, device=DEV, precision="bf16")
+        return render_path(torch.tensor(c2ws[ids]), (H, W, focals[ids]), 4096, kw, kp=torch.tensor(kps[ids]),
+                           skts=torch.tensor(skts[ids]), cams=cams[ids], white_bkgd=True, ret_acc=True,
+                           ext_scale=cfg.ext_scale)[0]
+
+    alone = [frames(p, np.arange(4)) for p in paths]
+    casters = [load_raycaster(p, cfg, device=DEV, precision="bf16")["ray_caster"] for p in paths]
+    assert len({id(c) for c in casters}) == 3                      # three resident casters, none reloaded
+    for f in range(4):                                              # interleaved: frame f of subject f % 3
+        s_ = f % 3
+        got = frames(paths[s_], np.array([f]))
+        assert np.array_equal(got[0], alone[s_][f])
+        assert load_raycaster(paths[s_], cfg, device=DEV, precision="bf16")["ray_caster"] is casters[s_]
+    assert not np.array_equal(alone[0], alone[1])
+
+
 def test_render_frame_equals_ray_level_path(caster):
     """pg_render_frame (rays generated, rendered and scattered on the device) against the
     ray-level route the reference takes: kp_to_valid_rays on the host -> render() -> scatter."""
