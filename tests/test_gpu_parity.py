@@ -113,11 +113,14 @@ def _oracle_stage(g, cfg, quant):
 # bone-local position as (R o + t) + z (R d) and factorise the view layer over rays, so a few
 # operands round the other way than in the oracle's direct form: the bound is ~1.5 operand ulps
 # of the largest |raw| (the error against the unrounded oracle is the same for both forms).
-@pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 4e-2),
-                                            (PREC_FP16, "fp16", 8e-3)]
-                         + [(PREC_BF16X3, None, 3e-3), (PREC_FP16C, "fp16c", 3e-4), (PREC_FP16C, None, 6e-4)]
-                         + ([(PREC_FP16X3, None, 2e-3)] if X3 else []))
-def test_stage_eval_coarse(casters, prec, quant, tol):
+# The exact-class modes are held to ~3x what they measure (fp32 3e-6 / 1.2e-5, bf16x3 9e-6 / 1.0e-4,
+# fp16c 1.0e-5 / 1.1e-4 against its emulation and 4e-4 against the unrounded oracle, at |raw| up to 13.6):
+# a layout bug of a single channel is O(1e-2) and cannot hide inside these.
+@pytest.mark.parametrize("prec,quant,tol0,tol", [(PREC_FP32, None, 2e-5, 4e-5), (PREC_BF16, "bf16", 4e-2, 4e-2),
+                                                 (PREC_FP16, "fp16", 8e-3, 8e-3)]
+                         + [(PREC_BF16X3, None, 4e-5, 3e-4), (PREC_FP16C, "fp16c", 4e-5, 3e-4), (PREC_FP16C, None, 4e-5, 9e-4)]
+                         + ([(PREC_FP16X3, None, 2e-3, 2e-3)] if X3 else []))
+def test_stage_eval_coarse(casters, prec, quant, tol0, tol):
     """raw (rgb_raw, sigma_raw) and the layer-0 pre-activation of the coarse net."""
     g = load_golden("rays_surreal")
     cfg = cfg_from_golden(g)
@@ -135,7 +138,7 @@ def test_stage_eval_coarse(casters, prec, quant, tol):
     dr = _maxdiff(raw.cpu().numpy(), ref.numpy())
     scale = float(ref.abs().max())
     print(f"[{PREC_NAMES[prec]}] layer0 preact maxdiff {d0:.3e}; raw maxdiff {dr:.3e} (|raw| max {scale:.1f})")
-    assert d0 <= tol
+    assert d0 <= tol0
     assert dr <= tol * max(1.0, scale / 10)
 
 
