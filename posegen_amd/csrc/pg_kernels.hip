@@ -297,7 +297,34 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
     }
     PG_WAVE_SYNC();
     // ---- stable merge of the S + n_imp depths by rank (== torch.sort of the concat) ----
+    // rank of element i = #{j : z_j < z_i or (z_j == z_i and j < i)}.  The coarse depths are increasing and,
+    // with deterministic u, so are the new ones (the inverse cdf is monotone): then
+    //   rank(coarse i) = i + #{new < z_i},   rank(new k) = k + #{coarse <= z_new[k]}
+    // by two binary searches (6 + 5 LDS reads per lane instead of 2 x 80).  Checked per ray (random draws
+    // give unsorted samples, a rounding quirk could): anything else takes the all-pairs count.
     const int NTOT = S + n_imp;
+    bool sorted = true;
+    for (int i = lane; i < NTOT - 1; i += 64)
+        if (i != S - 1 && sh_z[wave][i + 1] < sh_z[wave][i]) sorted = false;
+    if (__builtin_amdgcn_ballot_w64(!sorted) == 0ull) {
+        const float* zc = sh_z[wave];
+        const float* zn = sh_z[wave] + S;
+        for (int i = lane; i < NTOT; i += 64) {
+            const float x = zc[i];
+            int lo = 0, hi;
+            if (i < S) {            // first new sample >= x
+                hi = n_imp;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zn[mid] < x) lo = mid + 1; else hi = mid; }
+            } else {                // first coarse sample > x
+                hi = S;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (zc[mid] <= x) lo = mid + 1; else hi = mid; }
+            }
+            const int rank = (i < S ? i : i - S) + lo;
+            z_fine[ray * NTOT + rank] = x;
+            if (order) order[ray * NTOT + rank] = i;
+        }
+        return;
+    }
     for (int i = lane; i < NTOT; i += 64) {
         const float x = sh_z[wave][i];
         int rank = 0;
