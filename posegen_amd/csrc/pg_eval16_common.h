@@ -19,6 +19,12 @@ template <typename V> struct Op;
 template <> struct Op<bf16x8> {
     using E = __bf16;
     static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(PG_MFMA_TURNS)
+        // experiment: the two waves of a SIMD take turns at the matrix pipe -- a wave raises its priority
+        // for the issue of an MFMA and drops it right behind, so the other wave's ready MFMA wins the next slot
+        asm volatile("s_setprio 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_setprio 0" : "+v"(c) : "v"(a), "v"(b));
+        return c;
+#endif
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ bf16x8 cvt(const float* x) {
