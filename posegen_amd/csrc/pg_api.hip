@@ -296,7 +296,11 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
     a.n_iters = (int)iters;
-    const long long max_wg = (long long)h->n_cu * (sa ? pg_eval16_wgs_per_cu() : 1);
+    // POSEGEN_MAX_WG (measurement aid): fewer persistent workgroups than CUs, to see how much of a pass's time
+    // is contention between CUs (the weight stream is pulled from L2 by every CU) rather than its own work
+    static const long long wg_cap = [] { const char* e = std::getenv("POSEGEN_MAX_WG"); return e ? std::atoll(e) : 0ll; }();
+    long long max_wg = (long long)h->n_cu * (sa ? pg_eval16_wgs_per_cu() : 1);
+    if (wg_cap > 0 && wg_cap < max_wg) max_wg = wg_cap;
     const int grid = (int)(iters < max_wg ? iters : max_wg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
@@ -591,12 +595,14 @@ int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double*
     PG_HIP(h, hipEventCreate(&e0));
     PG_HIP(h, hipEventCreate(&e1));
     hipStream_t s = h->own_stream ? h->own_stream : nullptr;
+    int blocks = h->n_cu;                               // POSEGEN_MAX_WG: fewer CUs (how the clock answers to the load)
+    if (const char* e = std::getenv("POSEGEN_MAX_WG")) { const int c = std::atoi(e); if (c > 0 && c < blocks) blocks = c; }
     int iters = 2000;                                   // ~1 ms per 1000 iterations of 32 MFMAs at 2 waves/SIMD
     float ms = 0.0f;
     int err = 0;
     for (int round = 0; round < 6; ++round) {           // grow until one launch lasts min_ms: the clock settles in ms
         (void)hipEventRecord(e0, s);
-        err = pg_launch_mfma_rate(f16, lds_fed, h->n_cu, iters, reinterpret_cast<float*>(h->ws), s);
+        err = pg_launch_mfma_rate(f16, lds_fed, blocks, iters, reinterpret_cast<float*>(h->ws), s);
         (void)hipEventRecord(e1, s);
         if (err || hipEventSynchronize(e1) != hipSuccess) break;
         (void)hipEventElapsedTime(&ms, e0, e1);
@@ -606,7 +612,7 @@ int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double*
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (err) return fail(h, PG_EHIP, "calibration launch failed: %s", hipGetErrorString((hipError_t)err));
-    const double flop = (double)h->n_cu * 8.0 * (double)iters * 32.0 * 32768.0;
+    const double flop = (double)blocks * 8.0 * (double)iters * 32.0 * 32768.0;
     *tflops = flop / (ms * 1e-3) / 1e12;
     if (ms_out) *ms_out = ms;
     return PG_OK;
