@@ -21,6 +21,7 @@
 #include "pg_eval16_common.h"
 
 namespace pgd {
+__device__ __forceinline__ int h_abl(int lane) { return lane >> 5; }
 using namespace pgp::A;
 
 // TAPS = the debug taps of pg_stage_eval compiled in: a separate instantiation, launched only when a dump
@@ -77,6 +78,24 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     } while (0)
     if (FACT && PG_PREFETCH && (int)blockIdx.x < a.n_iters) PG_PREFETCH_PASS(blockIdx.x);
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+#if defined(PG_ABL_HIDDEN_ONLY)     // timing ablation only (wrong results): a pass = 11 hidden layers (1408 MFMAs),
+        {                           // no table, no embedding, no heads -- the ring/DMA/barrier machinery by itself
+            V fa_[HU], fb_[HU];
+            float t_[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t_[k] = 0.01f * (float)(lane + k) - 0.3f;
+#pragma unroll
+            for (int u = 0; u < HU; ++u) fa_[u] = Op<V>::cvt(t_);
+#pragma clang loop unroll(full)
+            for (int l = 0; l < 11; ++l) {
+                if (l & 1) hidden_layer<V>(fb_, fa_, st, 0, bias, BT_LAYER0 + NT, h_abl(lane));
+                else hidden_layer<V>(fa_, fb_, st, 0, bias, BT_LAYER0 + NT, h_abl(lane));
+            }
+            const long long gp_ = (long long)it * PTS + wave * 32 + (lane & 31);
+            if (gp_ < a.n_points && lane < 32) a.raw[gp_ * 4] = (float)fb_[0][0] + (float)fb_[HU - 1][3];
+            continue;
+        }
+#endif
         PG_STAMP(0);
         const long long p0 = (long long)it * PTS;
         const long long plast = min(p0 + PTS - 1, a.n_points - 1);
