@@ -269,7 +269,8 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     int rc = ensure_stream(h, which, prec, fact);
     if (rc) return rc;
-    const bool small = fact && use_small_tiles();
+    const bool sa = is_shape_a(prec);
+    const bool small = sa && fact && use_small_tiles();           // the opt-in variants exist for bf16 / fp16 only
     if (small && (rc = ensure_stream_s(h, which, prec))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
@@ -290,7 +291,6 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.tau_v = h->tau[0];
     a.tau_d = h->tau[1];
     a.dbg_stage = dbg_stage;
-    const bool sa = is_shape_a(prec);
     const int pts = sa ? pg_eval16_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
     if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
         return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
@@ -313,7 +313,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
     int e = small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : (fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
+          : (sa && fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
           : compk ? pg_launch_evalc(&a, fc, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
