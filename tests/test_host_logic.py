@@ -289,3 +289,23 @@ def test_training_draws_follow_the_reference_places_and_test_mode():
     assert 0 <= float(r["t_rand"].min()) and float(r["t_rand"].max()) < 1
     assert abs(float(r["noise0"].std()) - 6.0) < 0.15 and abs(float(r["noise1"].std()) - 6.0) < 0.15
     assert abs(float(r["ray_noise"].std()) - 0.5) < 0.01
+
+
+def test_host_packer_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The weight packer (pg_pack.cpp) is the host-side native code with real index arithmetic: every
+    precision x program x frame-code combination under ASan + UBSan on the CPU (GPU sanitizers are not
+    available on the pool)."""
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("ROCm clang++ not found")
+    exe = str(tmp_path / "pack_asan")
+    csrc = os.path.join(REPO, "posegen_amd", "csrc")
+    build = subprocess.run([clang, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-fno-omit-frame-pointer", "-I", csrc, os.path.join(REPO, "tools", "sanitize", "pack_asan.cpp"),
+                            os.path.join(csrc, "pg_pack.cpp"), "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitizer" in build.stderr.lower() and "cannot find" in build.stderr.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
+    assert "packer clean under ASan/UBSan" in run.stdout
