@@ -1,6 +1,6 @@
-"""Randomised frame-level parity on the GPU: posegen_amd.render.render_path (device boxes optional, bbox cull,
-chunk groups, background composite) against the oracle's render_path on random poses and jittered cameras,
-through the host-box route and through the all-device route (pg_pose_kinematics + pg_pose_boxes).
+"""Randomised frame-level parity on the GPU: posegen_amd.render.render_path (bbox cull, chunk groups, background
+composite, frame codes) against the oracle's render_path on random poses and jittered cameras.  (The all-device
+route -- pg_pose_kinematics + pg_pose_boxes -- is held bitwise to this one by tests/test_gpu_frames.py.)
 
     python tools/frame_sweep.py [--cases 6]
 
