@@ -434,6 +434,16 @@ __device__ __forceinline__ void y_stage(const YWeights<V, FC>& yw, uint8_t* rt, 
     const uint8_t* trow = rt + min(col, nr - 1) * SLOTF_BYTES + SLOTF_T16 + hl * 16;
     const uint8_t* trow_h = trow + hw * (JH * TK * 2);
     uint8_t* ybase = rt + SLOTF_Y + ((t * 2) * 64 + 32 * hw + col) * 16 + 4 * hl * SLOTF_BYTES;
+    // The wave's joints e = 0..NE-1 of one (ray, out channel) are the 16-bit slots e%8 of the 16 bytes a lane of
+    // the second stage's A fragment (tile, e/8) holds: they are collected in registers and written as TWO 16-byte
+    // stores per ray (64 lanes x 16 B contiguous: conflict-free) instead of NE 2-byte stores at a 16-byte lane
+    // stride (8-way bank conflicts, 100 LDS stores per wave and pass).
+    unsigned pk[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pk[r][q] = 0u;
+    float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma clang loop unroll(full)
     for (int e = 0; e < NE; ++e) {
         const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
@@ -445,10 +455,25 @@ __device__ __forceinline__ void y_stage(const YWeights<V, FC>& yw, uint8_t* rt, 
         acc = Op<V>::mfma(a0, __builtin_bit_cast(V, yw.b[2 * e]), acc);
         acc = Op<V>::mfma(a1, __builtin_bit_cast(V, yw.b[2 * e + 1]), acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)        // ray = r + 4 hl; only MAXR_F = 5 slots exist
-            if (hl == 0 || r == 0)
-                *reinterpret_cast<E*>(ybase + r * SLOTF_BYTES + (e / 8) * 1024 + (e % 8) * 2) = (E)acc[r];
+        for (int r = 0; r < 4; ++r) {      // ray = r + 4 hl
+            if ((e & 1) == 0 && e + 1 < NE) prev[r] = acc[r];
+            else {
+                const E lo = (E)((e & 1) ? prev[r] : acc[r]);
+                const E hi = (E)((e & 1) ? acc[r] : 0.0f);
+                unsigned short ulo, uhi;
+                __builtin_memcpy(&ulo, &lo, 2);
+                __builtin_memcpy(&uhi, &hi, 2);
+                pk[r][(e / 8) * 4 + (e % 8) / 2] = (unsigned)ulo | ((unsigned)uhi << 16);
+            }
+        }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)            // only MAXR_F = 5 slots exist: rays 0..3 from lanes < 32, ray 4 from the others
+        if (hl == 0 || r == 0) {
+#pragma unroll
+            for (int g = 0; g < (NE + 7) / 8; ++g)
+                *reinterpret_cast<uint4*>(ybase + r * SLOTF_BYTES + g * 1024) = make_uint4(pk[r][4 * g], pk[r][4 * g + 1], pk[r][4 * g + 2], pk[r][4 * g + 3]);
+        }
 }
 
 // second stage: acc[t] += sum_j w_j Y[ray][j][32t..] for the (at most two) rays of the wave
