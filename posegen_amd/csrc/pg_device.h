@@ -230,7 +230,9 @@ constexpr int LDS_CUT = LDS_BIAS + BIAS_FLOATS * 4;          // 48 floats
 constexpr int LDS_RTAB = LDS_CUT + 48 * 4;                   // MAXR slots
 constexpr int LDS_TOTAL = LDS_RTAB + MAXR * SLOT_FLOATS * 4;
 static_assert(LDS_BIAS % 16 == 0 && LDS_CUT % 16 == 0 && LDS_RTAB % 16 == 0, "LDS alignment");
+#if !defined(PG_RING_EXPERIMENT)      // ring-depth experiments of ONE kernel: the others' layouts need not fit
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
+#endif
 
 // q = (skt @ [p;1]).xyz with skt rows 0..2 at sk[0..11]      (core/encoders.py:8-23)
 __device__ __forceinline__ void bone_local(const float* sk, float px, float py, float pz,

@@ -315,7 +315,9 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
 
 // ===================== factorised view layer (pg_layout.h) ===============================
 constexpr int LDS_TOTAL_F = LDS_RTAB + MAXR_F * SLOTF_BYTES;
+#if !defined(PG_RING_EXPERIMENT)
 static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view layer)");
+#endif
 
 // Per-ray slots of the factorised path, one thread per (ray, joint):
 //   AB[j] = (a = R_j o + t_j, b = R_j d)                      (core/encoders.py:8-37)
