@@ -113,6 +113,7 @@ struct Stream {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) prefetch_next();
         rd_off = (uint32_t)(NSLOT - 1) * CHUNK_BYTES + lane * 16;   // advanced by the first enter()
+        rd_nxt = lane * 16;
     }
 #if defined(PG_STAMPS)
     unsigned long long t_vm = 0, t_bar = 0;
@@ -143,6 +144,7 @@ struct Stream {
     // relies on it).  Issued as one burst right after the barrier, the 8 waves' pieces queue up
     // in the texture addresser and every wave stalls on the issue.
     uint32_t cur_src, cur_dst;   // stream byte offset / ring byte offset of this wave's share
+    uint32_t rd_nxt;             // this lane's ring offset for the chunk AFTER the current one (enter_ahead / issue_ahead)
     __device__ __forceinline__ void enter_split() {
 #if defined(PG_STAMPS)
         unsigned long long s0, s1, s2;
@@ -166,6 +168,28 @@ struct Stream {
         rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES
                                                                                   : rd_off + CHUNK_BYTES;
         asm volatile("" : "+v"(rd_off)::"memory");
+    }
+    // Chunk entry with the data of the NEXT chunk confirmed as well (needs DEPTH >= 3, i.e. a ring of >= 4
+    // slots): a wave waits for its pieces of chunk c+1 too before the barrier, so behind the barrier every wave
+    // knows that chunks c and c+1 have landed, and reads of chunk c+1 may be issued BEFORE the barrier of its own
+    // entry (issue_ahead).  The A-fragment pipe then runs across chunk boundaries instead of restarting empty
+    // behind every barrier (an LDS latency exposed per chunk with one wave per SIMD).  The barrier of entry(c+1)
+    // still says "everyone is done reading chunk c" before its slot is refilled; this wave's reads of chunk c
+    // are complete by then because its last MFMA of the chunk waited for them (LGKM returns in order), so
+    // no lgkmcnt(0) is needed and the reads already in flight for chunk c+1 stay in flight.
+    __device__ __forceinline__ void enter_ahead() {
+        static_assert(DEPTH >= 3 || NSLOT < 4, "enter_ahead needs three chunks in flight");
+        if (dma_wave()) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH >= 3 ? DEPTH - 2 : 0) * PER) : "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_src = next_off + (wave - dma_base()) * (PER * 1024);
+        cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
+        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
+        asm volatile("" : "+s"(next_off), "+s"(fill_slot), "+s"(cur_src), "+s"(cur_dst));
+        rd_off = rd_nxt;
+        rd_nxt = rd_nxt + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_nxt - (NSLOT - 1) * CHUNK_BYTES
+                                                                                  : rd_nxt + CHUNK_BYTES;
+        asm volatile("" : "+v"(rd_off), "+v"(rd_nxt)::"memory");
     }
     // One refill piece, issued by asm in the SGPR-base + 32-bit lane offset form: through the
     // builtin hipcc forms a 64-bit VGPR address (a v_lshl_add_u64) for every one of the ~224
@@ -200,6 +224,18 @@ struct Stream {
             PG_ISSUE_CASE(18) PG_ISSUE_CASE(19) PG_ISSUE_CASE(20) PG_ISSUE_CASE(21) PG_ISSUE_CASE(22) PG_ISSUE_CASE(23)
             PG_ISSUE_CASE(24) PG_ISSUE_CASE(25) PG_ISSUE_CASE(26) PG_ISSUE_CASE(27) PG_ISSUE_CASE(28) PG_ISSUE_CASE(29)
             PG_ISSUE_CASE(30) PG_ISSUE_CASE(31)
+#undef PG_ISSUE_CASE
+            default: __builtin_unreachable();
+        }
+    }
+    // the same read from the chunk AFTER the current one (enter_ahead)
+    template <typename R>
+    __device__ __forceinline__ void issue_ahead(R& dst, int pos) const {
+        const unsigned addr = ring_lds + rd_nxt;
+        switch (pos) {
+#define PG_ISSUE_CASE(P) case P: asm volatile("ds_read_b128 %0, %1 offset:" #P "*1024" : "=v"(dst) : "v"(addr)); break;
+            PG_ISSUE_CASE(0) PG_ISSUE_CASE(1) PG_ISSUE_CASE(2) PG_ISSUE_CASE(3) PG_ISSUE_CASE(4) PG_ISSUE_CASE(5)
+            PG_ISSUE_CASE(6) PG_ISSUE_CASE(7) PG_ISSUE_CASE(8) PG_ISSUE_CASE(9) PG_ISSUE_CASE(10) PG_ISSUE_CASE(11)
 #undef PG_ISSUE_CASE
             default: __builtin_unreachable();
         }

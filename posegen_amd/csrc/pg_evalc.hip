@@ -130,6 +130,39 @@ __device__ __forceinline__ void piece_c(PairPipe<NS>& p, const ST& st, int i) {
     }
 }
 
+#if PG_RING_SLOTS >= 4
+// Continuous pair pipe (ring of >= 4 slots, Stream::enter_ahead): the reads of the first pairs of a chunk are
+// issued during the last pairs of the chunk before, so nothing restarts behind a chunk barrier; the pipe is
+// empty only at the start of a segment.
+template <int NS, typename ST>
+__device__ __forceinline__ void issue_pair(PairPipe<NS>& p, const ST& st, int P, int cur_chunk) {
+    const int q = P % PPC;
+    if (P / PPC == cur_chunk) { st.issue(p.r[P % NS][0], 2 * q); st.issue(p.r[P % NS][1], 2 * q + 1); }
+    else { st.issue_ahead(p.r[P % NS][0], 2 * q); st.issue_ahead(p.r[P % NS][1], 2 * q + 1); }
+}
+template <int TP, int NS, typename ST>
+__device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
+    constexpr int LA = NS - 1;
+    static_assert(LA <= 6, "issue_ahead covers the first 12 units of the next chunk");
+    if (P % PPC != 0) return;
+    st.enter_ahead();
+    if (P != 0) return;                                  // the pipe is already running
+#pragma clang loop unroll(full)
+    for (int k = 0; k < LA; ++k)
+        if (k < TP) issue_pair(p, st, k, 0);
+    retire_pair(p.r[0][0], p.r[0][1], 2 * (min(LA, TP) - 1));
+}
+template <int TP, int NS, typename ST>
+__device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
+    constexpr int LA = NS - 1;
+    const int q = P % PPC;
+    if (P + LA < TP) issue_pair(p, st, P + LA, P / PPC);
+    if (q & 1) piece_c(p, st, q >> 1);
+    if (P == TP - 1)            // a segment ending inside the chunk flushes the rest of the refill
+        for (int i = (q + 1) >> 1; i < ST::PER; ++i) piece_c(p, st, i);
+    if (P + 1 < TP) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], 2 * (min(P + LA, TP - 1) - (P + 1)));
+}
+#else
 // before the first MFMA of pair P (of a segment with TP pairs): chunk entry, and the pair must be there
 template <int TP, int NS, typename ST>
 __device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
@@ -154,6 +187,8 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
         for (int i = (q + 1) >> 1; i < ST::PER; ++i) piece_c(p, st, i);
     if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], 2 * min(LA - 1, rem - 1));
 }
+
+#endif
 
 // One k-major segment: NU input units against NO out tiles, `src(u, e)` = value e of unit u (indices
 // are compile-time constants after unrolling).  While the 2 NO MFMAs of unit u issue, unit u+1 is
