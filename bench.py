@@ -51,6 +51,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision side measurements")
     ap.add_argument("--no-extras", action="store_true", help="skip host_to_host / workloads / cpu_baselines")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: one all-hit frame per GPU per step (the headline); strong: --frames culled frames per step "
+                         "shared by all GPUs through dist.render_frames_distributed (the GAN loop's call pattern)")
+    ap.add_argument("--frames", type=int, default=20, help="frames per step of --scaling strong (run_gan.py:104: rpi = 20)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling side measurement of the default run")
     ap.add_argument("--dry-run", action="store_true", help="stub renderer on CPU, gloo backend (plumbing test)")
     return ap.parse_args(argv)
 
@@ -146,16 +151,23 @@ def timed_rays(r, dev, rb, skts, cyl, cfg, steps, cams=None):
     return rb.shape[0] * steps / dt, dt / steps * 1e3, tf, ms / max(launches, 1)
 
 
-def host_to_host(caster, cfg, dev, H, W, frames=4):
-    """pose tensors on host -> rgb/disp/acc frames on host, reference bbox cull."""
+def host_to_host(caster, cfg, dev, H, W, frames=4, all_hit=False):
+    """pose tensors on host -> rgb/disp/acc frames on host, reference bbox cull.  all_hit: the
+    headline workload's cylinder (radius 2.5: every ray hits, the box is the whole frame up to the excluded
+    `br` row / column) instead of the poses' own bounding cylinders."""
     import torch
     from posegen_amd import synthetic as syn
     from posegen_amd.render import render_path
+    from posegen_amd.skeleton import get_kp_bounding_cylinder
     _, kps, skts = syn.make_pose(frames, 1)
     c2ws, focals = syn.make_camera(frames, H, W)
+    cyls = None
+    if all_hit:
+        cyls = torch.tensor(get_kp_bounding_cylinder(kps, ext_scale=0.001), dtype=torch.float32)
+        cyls[:, 2] = 2.5
     kps, skts, c2ws = torch.tensor(kps), torch.tensor(skts), torch.tensor(c2ws)
     kw = {"ray_caster": caster, "N_importance": cfg.n_importance, "N_samples": cfg.n_samples, "lindisp": False}
-    run = lambda: render_path(c2ws, (H, W, focals), 4096, kw, kp=kps, skts=skts, white_bkgd=True, ret_acc=True,
+    run = lambda: render_path(c2ws, (H, W, focals), 4096, kw, kp=kps, skts=skts, cyls=cyls, white_bkgd=True, ret_acc=True,
                               ext_scale=cfg.ext_scale)
     out = run()
     n_valid = sum(len(v) for v in out[3])
@@ -169,7 +181,9 @@ def host_to_host(caster, cfg, dev, H, W, frames=4):
     return {"valid_rays_per_s": n_valid / dt, "pixels_per_s": frames * H * W / dt, "ms_per_frame": dt / frames * 1e3,
             "frames": frames, "valid_rays": n_valid,
             "what": f"render_path: {frames} poses + cameras on host -> float32 rgb/disp/acc frames {H}x{W} on host, "
-                    "reference bounding-cylinder cull (rays counted = rays inside the box), chunk 4096, "
+                    + ("all-hit cylinder of the headline workload (radius 2.5; rays counted = rays inside the box = the frame "
+                       "without its last row and column), chunk 4096, " if all_hit else
+                       "reference bounding-cylinder cull (rays counted = rays inside the box), chunk 4096, ") +
                     "includes box projection on the host, per-frame launches and the device->host copies"}
 
 
@@ -178,6 +192,54 @@ def dry_run_step(n, rank):
     import torch
     v = torch.arange(n, dtype=torch.float32)[:, None] * 1e-3 + rank
     return {"rgb_map": v.expand(n, 3), "disp_map": v[:, 0], "acc_map": v[:, 0]}
+
+
+class _DryRenderer:
+    """--dry-run stand-in for HipRenderer on the strong-scaling path: deterministic maps, no GPU."""
+    def __init__(self):
+        import torch
+        self.device = torch.device("cpu")
+    def set_chunk(self, c):
+        self.chunk = c
+    def render_frame_range(self, H, W, focal, c2w, box, skts, cyl, r0, r1, **kw):
+        import torch
+        i = torch.arange(r0, r1, dtype=torch.float32)
+        return torch.cat([torch.stack([i % 3, i % 5, i % 7], -1).reshape(-1) / 8, 1 + i * 0, (i % 2) * 0.5])
+    def compose_frame(self, H, W, box, rgb_map, disp_map, acc_map, bg=None, base_bg=0., **kw):
+        import torch
+        (tlx, tly), (brx, bry) = box
+        rgb = torch.full((H, W, 3), float(base_bg)); disp = torch.zeros(H, W, 1); acc = torch.zeros(H, W, 1)
+        bh, bw = bry - tly, brx - tlx
+        rgb[tly:bry, tlx:brx] = rgb_map.view(bh, bw, 3); disp[tly:bry, tlx:brx] = disp_map.view(bh, bw, 1)
+        acc[tly:bry, tlx:brx] = acc_map.view(bh, bw, 1)
+        return rgb, disp, acc
+
+
+class _DryCaster:
+    def __init__(self):
+        self.renderer = _DryRenderer()
+    module = property(lambda self: self)
+
+
+def strong_workload(caster, cfg, H, W, frames, group=None):
+    """BASELINE config 5's call pattern: `frames` poses at H x W with the reference's bounding-cylinder cull, one
+    camera, white background; one step = one dist.render_frames_distributed call (every rank renders its share
+    of the frames' nanmean groups, ONE all-gather, frames composed on every rank).  Returns (step, valid rays)."""
+    import torch
+    from posegen_amd import synthetic as syn
+    from posegen_amd.dist import render_frames_distributed
+    _, kps, skts = syn.make_pose(frames, 1)
+    c2ws, focals = syn.make_camera(frames, H, W)
+    kps, skts, c2ws = torch.tensor(kps), torch.tensor(skts), torch.tensor(c2ws)
+    kw = {"ray_caster": caster, "N_importance": cfg.n_importance, "N_samples": cfg.n_samples, "lindisp": False}
+    state = {}
+
+    def step():
+        out = render_frames_distributed(c2ws, (H, W, focals), cfg.chunk, kw, group=group, kp=kps, skts=skts,
+                                        white_bkgd=True, ext_scale=cfg.ext_scale)
+        state["valid"] = sum(len(v) for v in out[3])
+        return out
+    return step, state
 
 
 def main():
@@ -222,8 +284,9 @@ def main():
         r.set_chunk(cfg.chunk)
     packed = torch.empty(n, 5, device=dev)
     gathered = torch.empty(world * n, 5, device=dev) if world > 1 else None
+    strong = a.scaling == "strong"
 
-    def step():
+    def weak_step():
         out = dry_run_step(n, rank) if a.dry_run else r.render_rays(
             rb, skts, cyl, n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
         if world > 1:           # reassemble the frames of all ranks: one all-gather, device to device
@@ -233,11 +296,21 @@ def main():
             dist.all_gather_into_tensor(gathered, packed)
         return out
 
+    strong_step, strong_state = strong_workload(_DryCaster() if a.dry_run else caster, cfg, H, W, a.frames)
+    step = strong_step if strong else weak_step
+
     def sync():
         if world > 1:
             dist.barrier()
         if not a.dry_run:
             torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(a.warmup):
         step()
@@ -253,13 +326,33 @@ def main():
     launches, k_ms, k_pts = r.profile_read() if r is not None else (0, 0.0, 0)
     if r is not None:
         r.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if a.dry_run:           # the gathered frames are every rank's frame, in rank order
-            for k in range(world):
-                assert float(gathered[k * n, 0]) == float(k), "all-gather order"
+    dt = max_over_ranks(dt)
+    if world > 1 and a.dry_run and not strong:      # the gathered frames are every rank's frame, in rank order
+        for k in range(world):
+            assert float(gathered[k * n, 0]) == float(k), "all-gather order"
+
+    # Strong scaling beside the weak headline, on every rank (it has a collective): the product's multi-GPU path
+    # (dist.render_frames_distributed: plan of nanmean groups, one all-gather, compose) on the GAN loop's call
+    # pattern -- `--frames` culled frames per step for ALL GPUs together -- so that a scaling run also says
+    # something about load balance.
+    side = None
+    if not strong and not a.no_strong:
+        strong_step()
+        sync()
+        reps = 2
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            strong_step()
+        sync()
+        sdt = max_over_ranks(time.perf_counter() - t1) / reps
+        from posegen_amd.dist import plan_tasks
+        side = {"scaling": "strong", "frames_per_step": a.frames, "valid_rays_per_step": strong_state["valid"],
+                "rays_per_s": strong_state["valid"] / sdt, "ms_per_step": sdt * 1e3, "ms_per_frame": sdt * 1e3 / a.frames,
+                "n_gpus": world,
+                "what": f"dist.render_frames_distributed: {a.frames} poses at {H}x{W}, reference bounding-cylinder cull, "
+                        f"nanmean groups of {cfg.chunk} rays planned over {world} rank(s), one all-gather of the packed maps "
+                        "inside the timed region, frames composed on every rank (device resident); rays counted = rays "
+                        "inside the boxes, whole job"}
 
     if rank != 0:
         if world > 1:
@@ -268,26 +361,37 @@ def main():
         return
 
     flops_pt = cfg.flops_per_point()
-    rays_s = world * n * a.steps / dt
+    rays_s = (strong_state["valid"] if strong else world * n) * a.steps / dt
     peak = PEAK_TFLOPS[a.prec]
     k_tflops = k_pts * flops_pt / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     kernel = {"bf16": "eval16_kernel", "fp16": "eval16_kernel", "fp16c": "evalc_kernel"}.get(a.prec, "eval32_kernel")
     result = {
         "metric": METRIC,
         "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None, "dtype": a.prec, "data": "synthetic (dry run: stub renderer, no GPU)" if a.dry_run else "synthetic",
-        "config": {"workload": f"surreal {H}x{W} full frame per GPU ({n} rays, all rays hit: cylinder radius 2.5), "
-                               f"{cfg.n_samples} coarse + {cfg.n_importance} importance samples/ray = "
-                               f"{cfg.evals_per_ray()} MLP evals/ray (coarse + fine net), seeded synthetic weights/pose",
-                   "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}" if world > 1 else "single GPU",
-                   "flop_per_ray": flops_pt * cfg.evals_per_ray()},
+        "config": ({"workload": f"surreal {H}x{W}, {a.frames} culled frames per step for all GPUs together "
+                                f"({strong_state['valid']} rays inside the boxes), {cfg.n_samples} coarse + {cfg.n_importance} "
+                                f"importance samples/ray = {cfg.evals_per_ray()} MLP evals/ray, dist.render_frames_distributed "
+                                "(nanmean groups planned over the ranks, one all-gather, frames composed on every rank)",
+                    "frames_per_step": a.frames, "parallelism": f"ray-group-parallel x{world}" if world > 1 else "single GPU",
+                    "flop_per_ray": flops_pt * cfg.evals_per_ray()} if strong else
+                   {"workload": f"surreal {H}x{W} full frame per GPU ({n} rays, all rays hit: cylinder radius 2.5), "
+                                f"{cfg.n_samples} coarse + {cfg.n_importance} importance samples/ray = "
+                                f"{cfg.evals_per_ray()} MLP evals/ray (coarse + fine net), seeded synthetic weights/pose",
+                    "frames_per_step_per_gpu": 1, "parallelism": f"image-parallel x{world}" if world > 1 else "single GPU",
+                    "flop_per_ray": flops_pt * cfg.evals_per_ray()}),
         "roofline": {"bound": "mfma", "kernel": f"{kernel} (fused embed+MLP)",
                      "achieved": k_tflops, "peak": peak, "unit": "TFLOP/s", "frac": k_tflops / peak,
                      "traffic": None, "launches": launches, "avg_launch_ms": k_ms / max(launches, 1),
                      "points_per_launch": k_pts / max(launches, 1), "flop_per_point": flops_pt,
-                     "end_to_end_frac": rays_s / world * flops_pt * cfg.evals_per_ray() / 1e12 / peak},
+                     "end_to_end_frac": rays_s / world * flops_pt * cfg.evals_per_ray() / 1e12 / peak,
+                     # the path's ALGORITHMIC HBM bytes are 44 B in + 20 B out per ray; the kernels'
+                     # counter traffic (`traffic`, per eval launch) is mostly the raw / z intermediates between them
+                     "algorithmic_bytes_per_ray": 64, "algorithmic_bytes_per_frame": 64 * n},
     }
+    if side is not None:
+        result["strong_scaling"] = side
     if a.dry_run:
         print(json.dumps(result))
         if world > 1:
@@ -330,13 +434,19 @@ def main():
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the
     # profiler on itself, so the committed measurement of the same build is attached.
     alg_bytes = 20 * k_pts / max(launches, 1)       # z in 4 B/point + raw out 16 B/point
-    for tname in (f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
+    for tname in (f"r3_{a.prec}_traffic.json", f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
-        if H == 512 and os.path.exists(tpath) and (a.prec == "bf16" or tname.startswith("r2_")):
+        if H == 512 and os.path.exists(tpath) and (a.prec == "bf16" or not tname.startswith("r1_")):
             tj = json.load(open(tpath))
             result["roofline"]["traffic"] = tj["hbm_bytes"]
             result["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{tname})"
-            result["roofline"]["algorithmic_bytes_per_launch"] = tj.get("algorithmic_bytes", alg_bytes)
+            # what ONE eval launch has to move given the kernel split: z in 4 B/point + raw out 16 B/point
+            result["roofline"]["intermediate_bytes_per_launch"] = tj.get("algorithmic_bytes", alg_bytes)
+            # against SURVEY 8(d)'s figure for the PATH (64 B/ray): a frame is 2 eval + 2 composite + 1 sampling
+            # launch; the composite launches re-read what the eval launches wrote
+            per_frame = tj.get("hbm_bytes_per_frame", 2 * tj["hbm_bytes"] + 2 * tj.get("composite_hbm_bytes", 0.95 * tj["hbm_bytes"]))
+            result["roofline"]["traffic_per_frame"] = per_frame
+            result["roofline"]["traffic_ratio"] = per_frame / (64.0 * n)
             break
 
     sel = ref = None
@@ -350,7 +460,7 @@ def main():
         err["disp_map(acc>1e-3)"] = float((got["disp_map"].cpu() - ref["disp_map"])[solid].abs().max()) if solid.any() else 0.0
         mse = float(((got["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean())
         result["parity"] = {"vs": "oracle (fp32 CPU port pinned to the reference's golden vectors)", "rays": int(len(sel)),
-                            "max_abs": err, "rgb_rmse": mse ** 0.5,
+                            "max_abs": err, "rgb_rmse": mse ** 0.5, "rgb_mse": mse,
                             "rgb_psnr_db": -10 * np.log10(max(mse, 1e-30))}
 
     if world == 1 and not a.no_modes:
@@ -367,12 +477,18 @@ def main():
                 got = r.render_rays(rb[sel.to(dev)], skts, cyl)
                 m["max_abs_rgb_vs_oracle"] = float((got["rgb_map"].cpu() - ref["rgb_map"]).abs().max())
                 m["max_abs_acc_vs_oracle"] = float((got["acc_map"].cpu() - ref["acc_map"]).abs().max())
+                mse_m = float(((got["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean())
+                m["rgb_mse_vs_oracle"] = mse_m
+                m["rgb_psnr_db_vs_oracle"] = -10 * np.log10(max(mse_m, 1e-30))
             modes[name] = m
         r.set_precision(a.prec)
         result["modes"] = modes
 
     if world == 1 and not a.no_extras:
         result["host_to_host"] = host_to_host(caster, cfg, dev, H, W)
+        # SURVEY 8(d)'s metric on the HEADLINE workload: the same all-hit frame, pose tensors on the host -> float
+        # frames on the host through render_path (the cylinder of radius 2.5 projects to the whole frame)
+        result["host_to_host_all_hit"] = host_to_host(caster, cfg, dev, H, W, frames=4, all_hit=True)
         # BASELINE config 4: h36m (128 coarse + 16 importance samples, 16-d frame codes), one full frame
         c4 = h36m_config()
         m4 = syn.make_model(c4, 0)

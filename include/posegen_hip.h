@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 4
+#define PG_ABI_VERSION 5
 
 /* error codes */
 #define PG_OK 0
@@ -221,13 +221,33 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
                     int n_samples, int n_importance, int flags, const float* bg, float base_bg,
                     float* rgb, float* disp, float* acc, uint8_t* rgb8);
 
+/* The two halves of pg_render_frame, for callers that spread ONE frame over several processes (one process per
+ * GPU, posegen_amd.dist: the counterpart of nn.DataParallel's scatter of a ray chunk over the GPUs,
+ * core/raycasters.py:157, run_gan.py:162): rays [ray_begin, ray_end) of the box's row-major ray list
+ * (kp_to_valid_rays order) -> their maps, device pointers rgb_map [ray_end-ray_begin,3], disp_map, acc_map
+ * [ray_end-ray_begin].  ray_begin must be 0 or a multiple of the nanmean group size (pg_set_chunk), so that the
+ * groups -- and with them every value -- are those of the whole frame rendered in one call.  Other arguments
+ * as pg_render_frame.  Asynchronous on `stream`. */
+int pg_render_frame_range(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
+                          const int* box, float near, float far, const float* skts, const float* cyl, float cam,
+                          int n_samples, int n_importance, int flags, int64_t ray_begin, int64_t ray_end,
+                          float* rgb_map, float* disp_map, float* acc_map);
+
+/* render_path's scatter of a box's maps over the background frame (run_nerf.py:98-137), alone: device maps of the
+ * WHOLE box (rgb_map [n_box,3], disp_map, acc_map [n_box], e.g. assembled from pg_render_frame_range pieces) ->
+ * rgb [H*W,3], disp, acc [H*W] (may be NULL), rgb8 (may be NULL), background as in pg_render_frame. */
+int pg_compose_frame(pg_handle* h, void* stream, int H, int W, const int* box, const float* rgb_map, const float* disp_map,
+                     const float* acc_map, const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8);
+
 /* Frames on all devices of the handle, host in / host out: replaces the frame loop of render_path
  * (run_nerf.py:27-147) together with nn.DataParallel's scatter / gather.
- * One host thread and one stream per device; whole frames go to devices by longest-processing-
- * time on the ray count of their boxes; with fewer frames than devices a frame's nanmean groups
- * (`chunk` consecutive rays) are cut into contiguous runs, rendered on several devices, gathered on
- * the frame's owner by device-to-device copies and composed there -- the result is bit-identical to
- * one device either way.  No collective on the data path.
+ * One host thread and one stream per device.  Work plan (pg_plan_frames): the unit is a nanmean group (`chunk`
+ * consecutive rays of a box); frames go to devices whole, largest first, while they fit under the per-device
+ * target load; the frames that do not fit -- the tail of a batch whose size is not a multiple of the device
+ * count (20 frames on 8 GPUs, run_gan.py:2042-2047), or every frame when there are fewer frames than devices --
+ * are cut into runs of whole groups that fill the devices up to the target, rendered there, gathered on the
+ * frame's owner by device-to-device copies (peer access is enabled at pg_create) and composed there.  The result
+ * is bit-identical to one device either way.  No collective on the data path.
  *   c2ws [F,3,4], intrinsics [F,4], boxes [F,4] (tl_x, tl_y, br_x, br_y), skts [F,24,4,4], cyls [F,5],
  *   cams [F] or NULL: HOST; bg HOST [H*W,3] or NULL (one background for all frames)
  *   rgbs [F,H,W,3] f32, disps [F,H,W], accs [F,H,W], rgb8 [F,H,W,3] u8: HOST outputs, any but one of
@@ -237,9 +257,10 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
                      const float* cams, int n_samples, int n_importance, int flags, const float* bg, float base_bg,
                      float* rgbs, float* disps, float* accs, uint8_t* rgb8);
 
-/* Host-only: the work plan pg_render_frames uses (tests): tasks (frame, ray_begin,
- * ray_end, worker, owner) for frames of n_rays[f] rays on n_workers devices with nanmean groups of
- * `chunk` rays.  out_tasks [cap,5] may be NULL to query n_tasks. */
+/* Host-only: the work plan pg_render_frames uses (and posegen_amd.dist.plan_tasks restates for the one-process-
+ * per-GPU path): tasks (frame, ray_begin, ray_end, worker, owner) for frames of n_rays[f] rays on n_workers
+ * devices with nanmean groups of `chunk` rays; every ray of every frame is in exactly one task, every cut is a
+ * multiple of `chunk`, the loads differ by about one group.  out_tasks [cap,5] may be NULL to query n_tasks. */
 int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk, int32_t* out_tasks, int cap,
                    int* n_tasks);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
-PG_ABI_VERSION = 4
+PG_ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -97,6 +97,11 @@ PROTOTYPES = {
     "pg_render_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pg_render_frame_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_int), C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+                                        C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pg_compose_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_plan_frames": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                  C.POINTER(C.c_int)]),
 }

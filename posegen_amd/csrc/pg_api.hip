@@ -382,6 +382,33 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
         if (rc) { pg_destroy(h); return rc; }
         h->peers.push_back(sub);
     }
+    // The gather of a cut frame (pg_render_frames phase B) is a device-to-device copy: it goes over xGMI only
+    // with peer access enabled in both directions, otherwise the runtime stages it through the host -- refused
+    // here rather than done silently (POSEGEN_ALLOW_STAGED_PEER=1 accepts the staged copies).
+    if (n_devices > 1) {
+        const char* ev = std::getenv("POSEGEN_ALLOW_STAGED_PEER");
+        const bool allow_staged = ev && ev[0] == '1';
+        for (int i = 0; i < n_devices; ++i)
+            for (int j = 0; j < n_devices; ++j) {
+                const int di = device_ids[i], dj = device_ids[j];
+                if (di == dj) continue;
+                int can = 0;
+                hipError_t pe = hipDeviceCanAccessPeer(&can, di, dj);
+                if (pe == hipSuccess && can) {
+                    pe = hipSetDevice(di);
+                    if (pe == hipSuccess) pe = hipDeviceEnablePeerAccess(dj, 0);
+                    if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
+                }
+                if ((pe != hipSuccess || !can) && !allow_staged) {
+                    const int rc = fail(nullptr, PG_EHIP, "pg_create: device %d cannot access device %d directly (%s); frame gathers would be "
+                                        "staged through the host (set POSEGEN_ALLOW_STAGED_PEER=1 to accept that)", di, dj,
+                                        pe != hipSuccess ? hipGetErrorString(pe) : "hipDeviceCanAccessPeer = 0");
+                    pg_destroy(h);
+                    return rc;
+                }
+            }
+        (void)hipSetDevice(h->device);
+    }
     *out = h;
     return PG_OK;
 }
@@ -595,24 +622,32 @@ int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double*
     PG_HIP(h, hipEventCreate(&e0));
     PG_HIP(h, hipEventCreate(&e1));
     hipStream_t s = h->own_stream ? h->own_stream : nullptr;
+    PG_HIP(h, hipDeviceSynchronize());                  // own_stream is not ordered behind the caller's stream, and ws is shared
     int blocks = h->n_cu;                               // POSEGEN_MAX_WG: fewer CUs (how the clock answers to the load)
     if (const char* e = std::getenv("POSEGEN_MAX_WG")) { const int c = std::atoi(e); if (c > 0 && c < blocks) blocks = c; }
     int iters = 2000;                                   // ~1 ms per 1000 iterations of 32 MFMAs at 2 waves/SIMD
+    int timed_iters = 0;                                // iterations of the launch `ms` belongs to
     float ms = 0.0f;
     int err = 0;
+    hipError_t herr = hipSuccess;
     for (int round = 0; round < 6; ++round) {           // grow until one launch lasts min_ms: the clock settles in ms
         (void)hipEventRecord(e0, s);
         err = pg_launch_mfma_rate(f16, lds_fed, blocks, iters, reinterpret_cast<float*>(h->ws), s);
         (void)hipEventRecord(e1, s);
-        if (err || hipEventSynchronize(e1) != hipSuccess) break;
-        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (err) break;
+        herr = hipEventSynchronize(e1);
+        if (herr == hipSuccess) herr = hipEventElapsedTime(&ms, e0, e1);
+        if (herr != hipSuccess) break;
+        timed_iters = iters;
         if (ms >= min_ms && round > 0) break;
         if (ms < min_ms) iters = (int)(iters * (ms > 0.05 ? 1.25 * min_ms / ms : 8.0)) + 1;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (err) return fail(h, PG_EHIP, "calibration launch failed: %s", hipGetErrorString((hipError_t)err));
-    const double flop = (double)blocks * 8.0 * (double)iters * 32.0 * 32768.0;
+    if (herr != hipSuccess) return fail(h, PG_EHIP, "calibration kernel failed: %s", hipGetErrorString(herr));
+    if (!(ms > 0.0f) || timed_iters <= 0) return fail(h, PG_EHIP, "calibration measured no time (%.3f ms over %d iterations)", ms, timed_iters);
+    const double flop = (double)blocks * 8.0 * (double)timed_iters * 32.0 * 32768.0;
     *tflops = flop / (ms * 1e-3) / 1e12;
     if (ms_out) *ms_out = ms;
     return PG_OK;
@@ -832,9 +867,8 @@ int frame_geom(pg_handle* h, int H, int W, const float* c2w, const float* intrin
     return PG_OK;
 }
 
-// Frame workspace of `h` for a box of n rays of which a range of at most n_range is rendered here:
-// ray_batch rows and cams of the range, the maps of the WHOLE box (a range writes at its offset, so
-// that a partner device's share can be copied in at the same offset), coarse-pass scratch of the range.
+// Frame workspace of `h`: ray_batch rows and cams of a range of n_range rays, the maps of a WHOLE box of
+// n rays (n = 0: none -- the range's maps live in a buffer of the caller), coarse-pass scratch of the range.
 int frame_ws(pg_handle* h, int64_t n, int64_t n_range, float** rays, float** cams, FrameMaps* maps, pg_outputs* scratch) {
     auto al = [](size_t b) { return (b + 255) & ~size_t(255); };
     const size_t b_rays = al((size_t)n_range * 44), b_cam = al((size_t)n_range * 4);
@@ -858,20 +892,25 @@ int frame_ws(pg_handle* h, int64_t n, int64_t n_range, float** rays, float** cam
     return PG_OK;
 }
 
-// rays [r0, r1) of the box (row-major ray list of kp_to_valid_rays) -> maps[r0 .. r1).  r0 must be a multiple of
-// the nanmean group size (`chunk`) unless it is 0, so that the groups are those of the whole frame.
+// rays [r0, r1) of the box (row-major ray list of kp_to_valid_rays).  r0 must be a multiple of the nanmean
+// group size (`chunk`) unless it is 0, so that the groups are those of the whole frame.  ext == nullptr:
+// the maps of the whole box are carved from the frame workspace and the range is written at its offset
+// (returned in *maps); otherwise the range's maps go to ext (rgb [r1-r0,3], disp, acc [r1-r0]).
 int frame_render_range(pg_handle* h, void* stream, const pgk::FrameGeom& g, int64_t r0, int64_t r1, const float* skts,
-                       const float* cyl, int n_samples, int n_importance, int flags, FrameMaps* maps) {
+                       const float* cyl, int n_samples, int n_importance, int flags, FrameMaps* maps, const FrameMaps* ext = nullptr) {
     const int64_t n = (int64_t)g.bw * g.bh;
     if (r0 < 0 || r1 > n || r0 > r1) return fail(h, PG_EINVAL, "frame range [%lld, %lld) outside the box of %lld rays", (long long)r0, (long long)r1, (long long)n);
     if (r0 % h->cfg.chunk != 0) return fail(h, PG_EINVAL, "frame range must start on a nanmean group boundary (chunk %d)", h->cfg.chunk);
     PG_HIP(h, hipSetDevice(h->device));
     float *rays, *cams;
     pg_outputs out{};
-    int rc = frame_ws(h, n, r1 - r0, &rays, &cams, maps, &out);
+    FrameMaps own{};
+    int rc = frame_ws(h, ext ? 0 : n, r1 - r0, &rays, &cams, &own, &out);
     if (rc) return rc;
+    if (maps) *maps = ext ? *ext : own;
     if (r1 == r0) return PG_OK;
-    out.rgb_map = maps->rgb_map + r0 * 3; out.disp_map = maps->disp_map + r0; out.acc_map = maps->acc_map + r0;
+    if (ext) { out.rgb_map = ext->rgb_map; out.disp_map = ext->disp_map; out.acc_map = ext->acc_map; }
+    else { out.rgb_map = own.rgb_map + r0 * 3; out.disp_map = own.disp_map + r0; out.acc_map = own.acc_map + r0; }
     const bool fc = h->cfg.framecode_ch > 0;
     int e = pg_launch_frame_rays(&g, r0, r1 - r0, rays, fc ? cams : nullptr, stream);
     if (e) return fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -902,6 +941,33 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
     return frame_compose(h, stream, g, maps, bg, base_bg, rgb, disp, acc, rgb8);
 }
 
+int pg_render_frame_range(pg_handle* h, void* stream, int H, int W, const float* c2w, const float* intrinsics,
+                          const int* box, float near, float far, const float* skts, const float* cyl, float cam,
+                          int n_samples, int n_importance, int flags, int64_t ray_begin, int64_t ray_end,
+                          float* rgb_map, float* disp_map, float* acc_map) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (!skts || !cyl || !rgb_map || !disp_map || !acc_map) return fail(h, PG_EINVAL, "pg_render_frame_range: null argument");
+    pgk::FrameGeom g{};
+    int rc = frame_geom(h, H, W, c2w, intrinsics, box, near, far, cam, &g);
+    if (rc) return rc;
+    const FrameMaps ext{rgb_map, disp_map, acc_map};
+    return frame_render_range(h, stream, g, ray_begin, ray_end, skts, cyl, n_samples, n_importance, flags, nullptr, &ext);
+}
+
+int pg_compose_frame(pg_handle* h, void* stream, int H, int W, const int* box, const float* rgb_map, const float* disp_map,
+                     const float* acc_map, const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8) {
+    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (H <= 0 || W <= 0 || !box || !rgb) return fail(h, PG_EINVAL, "pg_compose_frame: null/non-positive argument");
+    pgk::FrameGeom g{};
+    const float c2w[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, intr[4] = {1.f, 1.f, 0.f, 0.f};
+    int rc = frame_geom(h, H, W, c2w, intr, box, 0.f, 1.f, -1.f, &g);
+    if (rc) return rc;
+    if ((int64_t)g.bw * g.bh > 0 && (!rgb_map || !disp_map || !acc_map)) return fail(h, PG_EINVAL, "pg_compose_frame: null map of a non-empty box");
+    PG_HIP(h, hipSetDevice(h->device));
+    const FrameMaps maps{const_cast<float*>(rgb_map), const_cast<float*>(disp_map), const_cast<float*>(acc_map)};
+    return frame_compose(h, stream, g, maps, bg, base_bg, rgb, disp, acc, rgb8);
+}
+
 int pg_pose_boxes(pg_handle* h, void* stream, int64_t n_poses, const float* kps, const double* w2c, int64_t w2c_stride,
                   const double* ring, double extension, double top_extension, double bot_extension, double fx, double fy,
                   int H, int W, int off_x, int off_y, float* cyls, int32_t* boxes) {
@@ -923,48 +989,59 @@ namespace {
 
 struct FrameTask { int frame; int64_t r0, r1; int worker; int owner; };
 
-// Whole frames to workers by longest-processing-time (ray count of the box); with fewer frames than
-// workers, a frame's nanmean groups (`chunk` consecutive rays) are cut into contiguous runs over
-// several workers, so that every group is rendered exactly as on one device.
+// Work plan of a frame batch on G workers (the call pattern of run_gan.py:2042-2047 is
+// 20 frames per call: whole frames alone would leave 3:2 loads on 8 GPUs).  The unit of work is a nanmean
+// group (`chunk` consecutive rays of a frame's box).  Frames go to workers whole, largest first, to the
+// least loaded worker, as long as they fit under the per-worker target (total rays / G, 2 % slack); the
+// frames that do not fit (the tail of a batch with F mod G != 0, or every frame when F < G) are cut into
+// contiguous runs of whole groups that fill the least loaded workers up to the target.  Every cut falls
+// on a multiple of `chunk`, so every group is rendered exactly as on one device.  A cut frame is composed
+// by its owner (the worker of its first run).  Deterministic; dist.plan_tasks is the same algorithm.
 void plan_frames(const std::vector<int64_t>& n_rays, int G, int chunk, std::vector<FrameTask>* tasks) {
     const int F = (int)n_rays.size();
+    tasks->clear();
+    if (F == 0) return;
     std::vector<int> order(F);
     for (int f = 0; f < F; ++f) order[f] = f;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_rays[a] > n_rays[b]; });
-    tasks->clear();
-    if (F >= G) {
-        std::vector<int64_t> load(G, 0);
-        for (int f : order) {
-            int w = 0;
-            for (int k = 1; k < G; ++k) if (load[k] < load[w]) w = k;
-            load[w] += n_rays[f];
-            tasks->push_back({f, 0, n_rays[f], w, w});
-        }
-        return;
-    }
-    // F < G: workers per frame proportional to its size (largest remainder), at least one each
     int64_t total = 0;
-    for (int64_t n : n_rays) total += n > 0 ? n : 1;
-    std::vector<int> share(F, 1);
-    int left = G - F;
-    std::vector<double> want(F);
-    for (int f = 0; f < F; ++f) want[f] = (double)(n_rays[f] > 0 ? n_rays[f] : 1) / (double)total * G;
-    while (left > 0) {
-        int best = 0;
-        for (int f = 1; f < F; ++f) if (want[f] - share[f] > want[best] - share[best]) best = f;
-        ++share[best];
-        --left;
-    }
-    int w = 0;
-    for (int f = 0; f < F; ++f) {
-        const int64_t groups = (n_rays[f] + chunk - 1) / chunk;
-        const int parts = (int)std::min<int64_t>(share[f], groups > 0 ? groups : 1);
-        const int owner = w;
-        for (int p = 0; p < parts; ++p) {
-            const int64_t g0 = groups * p / parts, g1 = groups * (p + 1) / parts;
-            tasks->push_back({f, std::min(g0 * chunk, n_rays[f]), std::min(g1 * chunk, n_rays[f]), w + p, owner});
+    for (int64_t n : n_rays) total += n > 0 ? n : 0;
+    const int64_t target = (total + G - 1) / G;
+    std::vector<int64_t> load(G, 0);
+    auto least = [&] {
+        int w = 0;
+        for (int k = 1; k < G; ++k) if (load[k] < load[w]) w = k;
+        return w;
+    };
+    std::vector<int> tail;
+    for (int f : order) {
+        const int w = least();
+        if (n_rays[f] <= chunk || load[w] + n_rays[f] <= target + target / 50) {
+            load[w] += n_rays[f] > 0 ? n_rays[f] : 0;
+            tasks->push_back({f, 0, n_rays[f] > 0 ? n_rays[f] : 0, w, w});
+        } else {
+            tail.push_back(f);
         }
-        w += share[f];          // workers beyond `parts` of a tiny frame stay idle
+    }
+    for (int f : tail) {
+        const int64_t groups = (n_rays[f] + chunk - 1) / chunk;
+        int64_t g = 0;
+        int owner = -1;
+        while (g < groups) {
+            const int w = least();
+            const int64_t cap = target - load[w];
+            int64_t take = cap > 0 ? (cap + chunk / 2) / chunk : 0;     // nearest whole number of groups
+            if (take < 1) take = 1;
+            if (take > groups - g) take = groups - g;
+            const int64_t rest = groups - g - take;
+            if (rest > 0 && rest * chunk <= std::max<int64_t>(chunk, target / 32)) take += rest;   // no sliver of a run for yet another worker
+            const int64_t r0 = g * chunk, r1 = std::min((g + take) * chunk, n_rays[f]);
+            if (owner < 0) owner = w;
+            if (!tasks->empty() && tasks->back().frame == f && tasks->back().worker == w && tasks->back().r1 == r0) tasks->back().r1 = r1;
+            else tasks->push_back({f, r0, r1, w, owner});
+            load[w] += r1 - r0;
+            g += take;
+        }
     }
 }
 
@@ -993,6 +1070,11 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
     if (n_frames < 0 || H <= 0 || W <= 0 || !c2ws || !intrinsics || !boxes || !skts || !cyls || (!rgbs && !rgb8))
         return fail(h, PG_EINVAL, "pg_render_frames: null/negative argument");
     if (n_frames == 0) return PG_OK;
+    // Worker 0 runs on the primary handle's own stream over the primary's workspaces: everything the caller
+    // queued on ITS stream (pg_render_rays / pg_render_frame are asynchronous and use the same buffers) must
+    // have finished first.  The call is synchronous anyway.
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipDeviceSynchronize());
     std::vector<pg_handle*> wk;
     wk.push_back(h);
     for (pg_handle* s : h->peers) wk.push_back(s);
@@ -1007,24 +1089,59 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
     }
     std::vector<FrameTask> tasks;
     plan_frames(nr, G, h->cfg.chunk, &tasks);
-    // the background (shared by all frames) once per worker that composes
-    struct Worker { pg_handle* h; int rc = PG_OK; float* d_bg = nullptr; std::vector<float*> bufs; hipEvent_t done = nullptr; };
+    // per worker: the frame buffers it composes into and the background (shared by all frames); per task of a
+    // cut frame: a buffer of its own for the range's maps (a worker may hold runs of several frames)
+    struct Worker { pg_handle* h; int rc = PG_OK; float* d_bg = nullptr; std::vector<float*> bufs; };
     std::vector<Worker> ws(G);
     for (int k = 0; k < G; ++k) ws[k].h = wk[k];
     std::vector<FrameMaps> maps_of(tasks.size());
+    std::vector<float*> part(tasks.size(), nullptr);
+    auto whole = [&](const FrameTask& tk) { return tk.r0 == 0 && tk.r1 == nr[tk.frame]; };
 
-    // phase A: every worker renders its ranges; whole frames are composed and copied out at once
+    auto checker = [&](Worker& w) {
+        return [&w](hipError_t e, const char* what) {
+            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(w.h, PG_EHIP, "%s failed on device %d: %s", what, w.h->device, hipGetErrorString(e));
+            return e == hipSuccess;
+        };
+    };
+    // frame buffers + background of a worker that composes
+    auto frame_bufs = [&](Worker& w) {
+        auto check = checker(w);
+        if (!w.bufs.empty()) return true;
+        float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
+        uint8_t* d_rgb8 = nullptr;
+        if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
+            !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
+            !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
+            (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return false;
+        w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
+        if (bg) {
+            if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
+                !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return false;
+        }
+        return true;
+    };
+    auto compose_out = [&](Worker& w, hipStream_t st, int f, const FrameMaps& maps) {
+        auto check = checker(w);
+        float *d_rgb = w.bufs[0], *d_disp = w.bufs[1], *d_acc = w.bufs[2];
+        uint8_t* d_rgb8 = reinterpret_cast<uint8_t*>(w.bufs[3]);
+        w.rc = frame_compose(w.h, st, geo[f], maps, w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
+        if (w.rc) return false;
+        if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return false;
+        if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return false;
+        if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return false;
+        if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return false;
+        return check(hipStreamSynchronize(st), "hipStreamSynchronize");      // the frame buffers are reused
+    };
+
+    // phase A: every worker renders its tasks; whole frames are composed and copied out at once, the runs of
+    // cut frames stay in their own buffers for the owner
     auto phase_a = [&](int k) {
         Worker& w = ws[k];
         pg_handle* hh = w.h;
-        auto check = [&](hipError_t e, const char* what) {
-            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(hh, PG_EHIP, "%s failed on device %d: %s", what, hh->device, hipGetErrorString(e));
-            return e == hipSuccess;
-        };
+        auto check = checker(w);
         if (!check(hipSetDevice(hh->device), "hipSetDevice")) return;
         hipStream_t st = hh->own_stream;
-        float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
-        uint8_t* d_rgb8 = nullptr;
         for (size_t t = 0; t < tasks.size() && w.rc == PG_OK; ++t) {
             const FrameTask& tk = tasks[t];
             if (tk.worker != k) continue;
@@ -1033,79 +1150,47 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
             if (!check(hipMemcpyAsync(hh->d_pose, skts + (size_t)f * 384, 384 * sizeof(float), hipMemcpyHostToDevice, st), "pose upload")) return;
             if (!check(hipMemcpyAsync(hh->d_pose + 384, cyls + (size_t)f * 5, 5 * sizeof(float), hipMemcpyHostToDevice, st), "cylinder upload")) return;
             if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;      // the host rows may be pageable
-            w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t]);
-            if (w.rc) return;
-            const bool whole = tk.r0 == 0 && tk.r1 == nr[f];
-            if (!whole) {
-                // the partner (or the owner itself) waits for this range before it gathers: one range per
-                // worker when frames are split, so a stream synchronisation at the end of phase A is enough
-                continue;
+            if (whole(tk)) {
+                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t]);
+                if (w.rc) return;
+                if (!frame_bufs(w) || !compose_out(w, st, f, maps_of[t])) return;
+            } else {
+                const size_t n = (size_t)(tk.r1 - tk.r0);
+                if (n == 0) continue;
+                if (!check(hipMalloc(reinterpret_cast<void**>(&part[t]), n * 20), "hipMalloc")) return;
+                const FrameMaps ext{part[t], part[t] + n * 3, part[t] + n * 4};
+                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t], &ext);
+                if (w.rc) return;
             }
-            if (!d_rgb) {
-                if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
-                    !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
-                    !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
-                    (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return;
-                w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
-                if (bg) {
-                    if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
-                        !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return;
-                }
-            }
-            w.rc = frame_compose(hh, st, geo[f], maps_of[t], w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
-            if (w.rc) return;
-            if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;      // the frame buffers are reused
         }
         check(hipStreamSynchronize(st), "hipStreamSynchronize");
     };
-    // phase B: the owner of a split frame gathers its partners' ranges (device to device), composes, copies out
+    // phase B: the owner of a cut frame gathers all its runs (device to device), composes, copies out
     auto phase_b = [&](int k) {
         Worker& w = ws[k];
         pg_handle* hh = w.h;
-        auto check = [&](hipError_t e, const char* what) {
-            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(hh, PG_EHIP, "%s failed on device %d: %s", what, hh->device, hipGetErrorString(e));
-            return e == hipSuccess;
-        };
+        auto check = checker(w);
         if (!check(hipSetDevice(hh->device), "hipSetDevice")) return;
         hipStream_t st = hh->own_stream;
-        for (size_t t = 0; t < tasks.size() && w.rc == PG_OK; ++t) {
-            const FrameTask& own = tasks[t];
-            if (own.owner != k || own.worker != k || (own.r0 == 0 && own.r1 == nr[own.frame])) continue;
-            const int f = own.frame;
+        for (int f = 0; f < n_frames && w.rc == PG_OK; ++f) {
+            bool mine = false;
+            for (const FrameTask& tk : tasks) mine = mine || (tk.frame == f && tk.owner == k && !whole(tk));
+            if (!mine) continue;
+            float *rays, *cams_d;
+            FrameMaps box{};
+            pg_outputs scratch{};
+            w.rc = frame_ws(hh, nr[f], 0, &rays, &cams_d, &box, &scratch);     // phase A is over: the workspace is free
+            if (w.rc) return;
             for (size_t u = 0; u < tasks.size(); ++u) {
                 const FrameTask& pt = tasks[u];
-                if (pt.frame != f || u == t || pt.r1 == pt.r0) continue;
+                if (pt.frame != f || pt.r1 == pt.r0) continue;
                 const int src_dev = wk[pt.worker]->device;
                 const size_t n = (size_t)(pt.r1 - pt.r0);
-                if (!check(hipMemcpyPeerAsync(maps_of[t].rgb_map + pt.r0 * 3, hh->device, maps_of[u].rgb_map + pt.r0 * 3, src_dev, n * 12, st), "peer copy") ||
-                    !check(hipMemcpyPeerAsync(maps_of[t].disp_map + pt.r0, hh->device, maps_of[u].disp_map + pt.r0, src_dev, n * 4, st), "peer copy") ||
-                    !check(hipMemcpyPeerAsync(maps_of[t].acc_map + pt.r0, hh->device, maps_of[u].acc_map + pt.r0, src_dev, n * 4, st), "peer copy")) return;
+                if (!check(hipMemcpyPeerAsync(box.rgb_map + pt.r0 * 3, hh->device, maps_of[u].rgb_map, src_dev, n * 12, st), "peer copy") ||
+                    !check(hipMemcpyPeerAsync(box.disp_map + pt.r0, hh->device, maps_of[u].disp_map, src_dev, n * 4, st), "peer copy") ||
+                    !check(hipMemcpyPeerAsync(box.acc_map + pt.r0, hh->device, maps_of[u].acc_map, src_dev, n * 4, st), "peer copy")) return;
             }
-            float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
-            uint8_t* d_rgb8 = nullptr;
-            if (w.bufs.empty()) {
-                if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
-                    !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
-                    !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
-                    (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return;
-                w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
-                if (bg) {
-                    if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
-                        !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return;
-                }
-            }
-            d_rgb = w.bufs[0]; d_disp = w.bufs[1]; d_acc = w.bufs[2]; d_rgb8 = reinterpret_cast<uint8_t*>(w.bufs[3]);
-            w.rc = frame_compose(hh, st, geo[f], maps_of[t], w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
-            if (w.rc) return;
-            if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return;
-            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;
+            if (!frame_bufs(w) || !compose_out(w, st, f, box)) return;
         }
     };
     auto run = [&](auto&& fn) {
@@ -1116,11 +1201,13 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
     };
     run(phase_a);
     bool split = false;
-    for (const FrameTask& tk : tasks) split = split || !(tk.r0 == 0 && tk.r1 == nr[tk.frame]);
+    for (const FrameTask& tk : tasks) split = split || !whole(tk);
     bool ok = true;
     for (const Worker& w : ws) ok = ok && w.rc == PG_OK;
     if (ok && split) run(phase_b);
     int rc = PG_OK;
+    for (size_t t = 0; t < tasks.size(); ++t)
+        if (part[t]) { (void)hipSetDevice(wk[tasks[t].worker]->device); (void)hipFree(part[t]); }
     for (Worker& w : ws) {
         (void)hipSetDevice(w.h->device);
         for (float* b : w.bufs) if (b) (void)hipFree(b);

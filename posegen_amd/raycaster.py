@@ -281,6 +281,59 @@ class HipRenderer:
             _ptr(rgb8)))
         return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
 
+    def _frame_args(self, H, W, focal, c2w, box, center):
+        f = np.asarray(focal.detach().cpu() if isinstance(focal, torch.Tensor) else focal, dtype=np.float64).reshape(-1)
+        fx, fy = (float(f[0]), float(f[0])) if f.size < 2 else (float(f[0]), float(f[1]))
+        cx, cy = (W * 0.5, H * 0.5) if center is None else (float(center[0]), float(center[1]))
+        c2w_h = np.ascontiguousarray(np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w,
+                                                dtype=np.float32)[:3, :4])
+        (tlx, tly), (brx, bry) = box
+        return (c2w_h, (C.c_float * 4)(fx, fy, cx, cy), (C.c_int * 4)(int(tlx), int(tly), int(brx), int(bry)))
+
+    def render_frame_range(self, H: int, W: int, focal, c2w, box, skts: torch.Tensor, cyl: torch.Tensor,
+                           ray_begin: int, ray_end: int, center=None, cam: Optional[float] = None, near: float = 0.,
+                           far: float = 1., n_samples: Optional[int] = None, n_importance: Optional[int] = None,
+                           lindisp: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Rays [ray_begin, ray_end) of the box's row-major ray list -> their maps, packed as one device tensor
+        [5, n]: rows 0-2 hold rgb_map [n,3] (flat), row 3 disp_map, row 4 acc_map (pg_render_frame_range; the
+        unit of work of the multi-process partition, dist.plan_tasks).  `ray_begin` must be 0 or a multiple
+        of the nanmean group size, so the values are those of the whole frame."""
+        cfg = self.cfg
+        S = cfg.n_samples if n_samples is None else int(n_samples)
+        N = cfg.n_importance if n_importance is None else int(n_importance)
+        n = int(ray_end) - int(ray_begin)
+        buf = torch.empty(5 * n, device=self.device) if out is None else out
+        if buf.numel() != 5 * n or buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise ValueError("render_frame_range: `out` must be a contiguous float32 tensor of 5 * n elements")
+        if n > 0:
+            c2w_h, intr, bx = self._frame_args(H, W, focal, c2w, box, center)
+            sk, _ = self._pose_args(skts, 1)
+            cy_t, _ = self._cyl_args(cyl, 1)
+            flat = buf.view(-1)
+            self._check(self.lib.pg_render_frame_range(
+                self.handle, self._stream(), int(H), int(W), c2w_h.ctypes.data_as(C.POINTER(C.c_float)), intr, bx,
+                float(near), float(far), _ptr(sk), _ptr(cy_t), -1.0 if cam is None else float(cam), S, N,
+                _ffi.PG_FLAG_LINDISP if lindisp else 0, int(ray_begin), int(ray_end),
+                _ptr(flat[:3 * n]), _ptr(flat[3 * n:4 * n]), _ptr(flat[4 * n:])))
+        return buf
+
+    def compose_frame(self, H: int, W: int, box, rgb_map: torch.Tensor, disp_map: torch.Tensor, acc_map: torch.Tensor,
+                      bg: Optional[torch.Tensor] = None, base_bg: float = 0., want_uint8: bool = False):
+        """The maps of a whole box over the background (pg_compose_frame): device tensors rgb [H,W,3],
+        disp [H,W,1], acc [H,W,1] (+ rgb8)."""
+        dev = self.device
+        (tlx, tly), (brx, bry) = box
+        rgb = torch.empty(H, W, 3, device=dev)
+        disp = torch.empty(H, W, 1, device=dev)
+        acc = torch.empty(H, W, 1, device=dev)
+        rgb8 = torch.empty(H, W, 3, device=dev, dtype=torch.uint8) if want_uint8 else None
+        bgt = None if bg is None else _dev_f32(bg.reshape(H * W, 3), dev)
+        rm, dm, am = (_dev_f32(rgb_map, dev), _dev_f32(disp_map, dev), _dev_f32(acc_map, dev))
+        self._check(self.lib.pg_compose_frame(
+            self.handle, self._stream(), int(H), int(W), (C.c_int * 4)(int(tlx), int(tly), int(brx), int(bry)),
+            _ptr(rm), _ptr(dm), _ptr(am), _ptr(bgt), float(base_bg), _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(rgb8)))
+        return (rgb, disp, acc, rgb8) if want_uint8 else (rgb, disp, acc)
+
     @property
     def n_devices(self) -> int:
         return len(self.devices)
@@ -551,15 +604,21 @@ class HipRayCaster:
             raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
         # One call = one nanmean group, like get_near_far_in_cylinder on the reference's ray_batch
         # (ray_utils.py:292-344): only batchify_rays / render_path split a frame into `chunk` groups.
+        # The group size is a property of THIS call: the renderer's own setting (what later direct
+        # render_rays / render_frame calls see) is put back afterwards.
+        keep = self.renderer._chunk
         if not getattr(self, "_grouped_call", False):
             self.renderer.set_chunk(max(int(ray_batch.shape[0]), 1))
-        if draws is None and (perturb or raw_noise_std or ray_noise_std):
-            S = self.cfg.n_samples if N_samples is None else int(N_samples)
-            draws = self.training_draws(int(ray_batch.shape[0]), S, int(N_importance or 0), perturb, raw_noise_std,
-                                        ray_noise_std, pytest=pytest)
-        return self.renderer.render_rays(ray_batch, skts, cyls, cams=cams, n_samples=N_samples,
-                                         n_importance=N_importance, lindisp=bool(lindisp),
-                                         want_alpha=want_alpha, extras=extras, draws=draws)
+        try:
+            if draws is None and (perturb or raw_noise_std or ray_noise_std):
+                S = self.cfg.n_samples if N_samples is None else int(N_samples)
+                draws = self.training_draws(int(ray_batch.shape[0]), S, int(N_importance or 0), perturb, raw_noise_std,
+                                            ray_noise_std, pytest=pytest)
+            return self.renderer.render_rays(ray_batch, skts, cyls, cams=cams, n_samples=N_samples,
+                                             n_importance=N_importance, lindisp=bool(lindisp),
+                                             want_alpha=want_alpha, extras=extras, draws=draws)
+        finally:
+            self.renderer.set_chunk(keep)
 
     def training_draws(self, n, S, N, perturb=0., raw_noise_std=0., ray_noise_std=0., pytest=False):
         return make_training_draws(n, S, N, perturb, raw_noise_std, ray_noise_std, pytest=pytest,
@@ -607,6 +666,19 @@ def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PR
     return {"ray_caster": caster, "perturb": False, "N_importance": cfg.n_importance,
             "N_samples": cfg.n_samples, "use_viewdirs": True, "raw_noise_std": 0., "ray_noise_std": 0.,
             "ext_scale": cfg.ext_scale, "preproc_kwargs": {}, "lindisp": cfg.lindisp, "nerf_type": "nerf"}
+
+
+def find_checkpoint(basedir: str, expname: str, ft_path: Optional[str] = None, no_reload: bool = False) -> Optional[str]:
+    """The checkpoint `create_raycaster` would reload (core/raycasters.py:124-141): `ft_path` if given (and not
+    the string 'None'), otherwise the LAST entry, in sorted name order, of basedir/expname whose name contains
+    'tar' and not 'pose'; None when there is none or `no_reload` is set."""
+    import os
+    if ft_path is not None and ft_path != "None":
+        ckpts = [ft_path]
+    else:
+        d = os.path.join(basedir, expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f and "pose" not in f]
+    return ckpts[-1] if ckpts and not no_reload else None
 
 
 _RAYCASTER_CACHE: Dict[tuple, dict] = {}

@@ -53,8 +53,8 @@ def kp_to_boxes(poses, H, W, focal, kps=None, cylinder_params=None, centers=None
         cyl = cylinder_params[i % n_pose]
         f = focal if isinstance(focal, float) else focal[i]
         center = None if centers is None else centers[i]
-        h = H if isinstance(H, int) else H[i]
-        w = W if isinstance(W, int) else W[i]
+        h = int(H) if isinstance(H, (int, np.integer)) else H[i]
+        w = int(W) if isinstance(W, (int, np.integer)) else W[i]
         c2w_np = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w)
         tl, br, _ = cylinder_to_box_2d(cyl.detach().cpu().numpy(), [h, w, f], nerf_c2w_to_extrinsic(c2w_np),
                                        center=center)

@@ -119,9 +119,9 @@ def render_frames_device(render_poses, hwf, chunk, render_kwargs, centers=None, 
         disps.append(disp_img)
         accs.append(acc_img)
     if not ids:
-        if not (isinstance(H, int) and isinstance(W, int)):
+        if not (isinstance(H, (int, np.integer)) and isinstance(W, (int, np.integer))):
             raise ValueError("an empty frame share needs scalar H, W to shape its (empty) result")
-        e = lambda c: torch.zeros((0, H, W, c), device=dev)
+        e = lambda c: torch.zeros((0, int(H), int(W), c), device=dev)
         return e(3), e(1), e(1), valid_idxs, bboxes
     rgbs, disps, accs = torch.stack(rgbs), torch.stack(disps), torch.stack(accs)
     disps = torch.nan_to_num(disps, nan=0.0, posinf=float("inf"), neginf=float("-inf"))   # run_nerf.py:142-143

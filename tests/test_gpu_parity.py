@@ -375,6 +375,10 @@ def test_render_rays_fast_modes(casters, name, prec, quant):
     assert e_emu <= 1.5e-3 if prec == PREC_BF16 else e_emu <= 5e-4
     assert e_ref <= b_rgb
     assert e_disp <= b_disp
+    # north_star: "within 1e-4 PSNR-equivalent".  Read as MSE <= 1e-4 (PSNR >= 40 dB, the reference's own metric,
+    # evaluation_helpers.py:346) the single-product modes pass with ~30 dB to spare; read as max-abs they do not
+    # (bound above) -- DESIGN.md section 3 states both.
+    assert mse <= 1e-4 and -10 * np.log10(max(mse, 1e-30)) >= 60.0
 
 
 @pytest.mark.parametrize("S,N,lindisp", [(64, 16, True), (192, 64, False), (256, 0, False), (32, 2, False), (240, 16, True)])

@@ -125,22 +125,37 @@ _GLOO_RENDER_WORKER = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from posegen_amd import synthetic as syn
-from posegen_amd.dist import render_path_distributed
+from posegen_amd.dist import plan_tasks, render_path_distributed
 from posegen_amd.render import render_path
 
-class StubRenderer:                       # stands in for HipRenderer: a frame = f(box, pose, camera)
+class StubRenderer:                       # stands in for HipRenderer: a ray's maps = f(box, pose, camera, ray index)
     device = torch.device("cpu")
-    calls = 0
+    rays = 0
     def set_chunk(self, c): self.chunk = c
-    def render_frame(self, H, W, focal, c2w, box, skts, cyl, center=None, cam=None, **kw):
-        StubRenderer.calls += 1
+    def render_frame_range(self, H, W, focal, c2w, box, skts, cyl, r0, r1, center=None, cam=None, **kw):
+        assert r0 == 0 or r0 % self.chunk == 0, "a run starts on a nanmean group boundary"
+        StubRenderer.rays += r1 - r0
         (tlx, tly), (brx, bry) = box
-        v = float(torch.as_tensor(skts).sum()) + float(np.asarray(c2w).sum())
-        rgb = torch.full((H, W, 3), 1.0); disp = torch.zeros(H, W, 1); acc = torch.zeros(H, W, 1)
-        rgb[tly:bry, tlx:brx] = v % 1.0
-        disp[tly:bry, tlx:brx] = float("nan")      # empty rays: NaN disparity -> 0 (run_nerf.py:142-143)
-        acc[tly:bry, tlx:brx] = (brx - tlx) / W
+        v = (float(torch.as_tensor(skts).sum()) + float(np.asarray(c2w).sum())) % 1.0
+        i = torch.arange(r0, r1, dtype=torch.float32)
+        rgb = torch.stack([v + 0 * i, (i % 7) / 7, (i % 5) / 5], -1)
+        disp = torch.full((r1 - r0,), float("nan"))        # empty rays: NaN disparity -> 0 (run_nerf.py:142-143)
+        acc = 0.5 + 0.25 * torch.sin(i)
+        return torch.cat([rgb.reshape(-1), disp, acc])
+    def compose_frame(self, H, W, box, rgb_map, disp_map, acc_map, bg=None, base_bg=0., **kw):
+        (tlx, tly), (brx, bry) = box
+        rgb = torch.full((H, W, 3), float(base_bg)); disp = torch.zeros(H, W, 1); acc = torch.zeros(H, W, 1)
+        bh, bw = bry - tly, brx - tlx
+        rgb[tly:bry, tlx:brx] = rgb_map.view(bh, bw, 3) + (1 - acc_map.view(bh, bw, 1)) * base_bg
+        disp[tly:bry, tlx:brx] = torch.nan_to_num(disp_map.view(bh, bw, 1), nan=0.0)
+        acc[tly:bry, tlx:brx] = acc_map.view(bh, bw, 1)
         return rgb, disp, acc
+    def render_frame(self, H, W, focal, c2w, box, skts, cyl, **kw):
+        (tlx, tly), (brx, bry) = box
+        n = (bry - tly) * (brx - tlx)
+        p = self.render_frame_range(H, W, focal, c2w, box, skts, cyl, 0, n)
+        StubRenderer.rays -= n
+        return self.compose_frame(H, W, box, p[:3 * n].view(n, 3), p[3 * n:4 * n], p[4 * n:], base_bg=kw.get("base_bg", 0.))
 class StubCaster:
     renderer = StubRenderer()
     module = property(lambda self: self)
@@ -148,20 +163,22 @@ class StubCaster:
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 H = W = 64
-for F in (1, 3):                          # F = 1 < world: rank 1 owns nothing and must still gather
+for F, hw in ((1, (H, W)), (3, (H, W)), (1, (np.int64(H), np.int64(W)))):     # F odd: a frame is cut between the two ranks
     _, kps, skts = syn.make_pose(F, 3)
     c2ws, focals = syn.make_camera(F, H, W)
     kw = dict(kp=torch.tensor(kps), skts=torch.tensor(skts), white_bkgd=True, ext_scale=0.001, ret_acc=True)
     rk = {"ray_caster": StubCaster(), "N_samples": 64, "N_importance": 16}
-    want = render_path(torch.tensor(c2ws), (H, W, focals), 4096, rk, **kw)
-    before = StubRenderer.calls
-    got = render_path_distributed(torch.tensor(c2ws), (H, W, focals), 4096, rk, **kw)
-    mine = StubRenderer.calls - before
+    want = render_path(torch.tensor(c2ws), (H, W, focals), 256, rk, **kw)
+    before = StubRenderer.rays
+    got = render_path_distributed(torch.tensor(c2ws), hw + (focals,), 256, rk, **kw)
+    mine = StubRenderer.rays - before
     for a, b in zip(want[:3], got[:3]):
         assert a.shape == b.shape and np.array_equal(a, b), (rank, F)
     assert np.array_equal(np.array(got[4]), np.array(want[4]))
+    total = sum(len(v) for v in want[3])
     n = torch.tensor([mine]); dist.all_reduce(n)
-    assert int(n) == F, "every frame rendered exactly once across the ranks"
+    assert int(n) == total, "every ray rendered exactly once across the ranks"
+    assert abs(mine - total / 2) <= 256 + total // 50, ("balanced to about one group", mine, total)
 dist.barrier()
 dist.destroy_process_group()
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ok_{rank}"), "w").write("ok")
@@ -185,10 +202,30 @@ def _run_world2(tmp_path, source):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()      # (stdout of the ranks interleaves)
 
 
-def test_render_path_distributed_gloo_world2_fewer_frames_than_ranks(tmp_path):
-    """render_path_distributed == render_path on every rank, including F = 1 on two ranks (the
-    rank with an empty share must reach the all-gather instead of dying in torch.stack([]))."""
+def test_render_path_distributed_gloo_world2_cut_frames(tmp_path):
+    """render_path_distributed == render_path on every rank: one frame on two ranks and three frames on two
+    ranks (a frame's nanmean groups are cut between the ranks, every ray rendered once, loads balanced to a
+    group), numpy-integer H / W included."""
     _run_world2(tmp_path, _GLOO_RENDER_WORKER)
+
+
+def test_render_path_distributed_without_a_process_group_is_the_single_device_render():
+    """No torch.distributed initialised: world 1, no collective, same frames as render_path."""
+    ns = {}
+    src = _GLOO_RENDER_WORKER.split("dist.init_process_group")[0].replace("sys.path.insert(0, sys.argv[1])", "")
+    exec(src, ns)
+    from posegen_amd.dist import render_path_distributed
+    from posegen_amd.render import render_path
+    from posegen_amd import synthetic as syn
+    H = W = 48
+    _, kps, skts = syn.make_pose(2, 3)
+    c2ws, focals = syn.make_camera(2, H, W)
+    kw = dict(kp=torch.tensor(kps), skts=torch.tensor(skts), white_bkgd=True, ext_scale=0.001, ret_acc=True)
+    rk = {"ray_caster": ns["StubCaster"](), "N_samples": 64, "N_importance": 16}
+    want = render_path(torch.tensor(c2ws), (H, W, focals), 256, rk, **kw)
+    got = render_path_distributed(torch.tensor(c2ws), (H, W, focals), 256, rk, **kw)
+    for a, b in zip(want[:3], got[:3]):
+        assert np.array_equal(a, b)
 
 
 def _plan(n_rays, workers, chunk):
@@ -203,15 +240,18 @@ def _plan(n_rays, workers, chunk):
 
 
 def test_frame_plan_covers_every_ray_once_on_group_boundaries():
-    """pg_plan_frames (the work plan of the in-process multi-GPU renderer): whole frames by LPT when there
-    are enough of them; otherwise a frame's nanmean groups are cut into contiguous runs, so every cut
-    falls on a multiple of `chunk` and the groups are those of the single-device render."""
+    """pg_plan_frames (the work plan of the in-process multi-GPU renderer) and dist.plan_tasks (the same plan for
+    one process per GPU): every ray of every frame in exactly one task, every cut on a multiple of `chunk` (the
+    groups are those of the single-device render), one owner per frame, loads within about a group of the mean --
+    also when the frame count is not a multiple of the worker count (20 frames on 8 GPUs)."""
+    from posegen_amd.dist import plan_tasks
     rng = np.random.RandomState(0)
     for workers in (1, 2, 3, 8):
-        for F in (1, 2, 5, 20):
+        for F in (1, 2, 5, 8, 9, 20):
             for chunk in (4096, 1000):
                 n = [int(x) for x in rng.randint(1, 200000, size=F)]
                 tasks = _plan(n, workers, chunk)
+                assert tasks == [tuple(t) for t in plan_tasks(n, workers, chunk)], "the library and dist.py plan alike"
                 for f in range(F):
                     runs = sorted((t[1], t[2]) for t in tasks if t[0] == f)
                     assert runs[0][0] == 0 and runs[-1][1] == n[f]
@@ -220,18 +260,23 @@ def test_frame_plan_covers_every_ray_once_on_group_boundaries():
                     owners = {t[4] for t in tasks if t[0] == f}
                     assert len(owners) == 1 and next(iter(owners)) in {t[3] for t in tasks if t[0] == f}
                 assert all(0 <= t[3] < workers for t in tasks)
-                if F >= workers:
-                    assert all(t[1] == 0 and t[2] == n[t[0]] for t in tasks)          # whole frames
-                    load = [sum(n[t[0]] for t in tasks if t[3] == w) for w in range(workers)]
-                    assert max(load) - min(load) <= max(n)
-                else:
-                    used = {t[3] for t in tasks}
-                    big = [f for f in range(F) if n[f] > chunk * workers]
-                    if len(big) == F:
-                        assert len(used) == workers                                    # nobody idles
+                load = [sum(t[2] - t[1] for t in tasks if t[3] == w) for w in range(workers)]
+                mean = sum(n) / workers
+                if mean >= 16 * chunk:                     # enough groups per worker for a balanced plan to exist
+                    assert max(load) <= 1.05 * mean + chunk, (workers, F, chunk, load)
+    # the GAN loop's call pattern: 20 frames on 8 devices (whole frames alone: 3:2 loads = 1.2 x the mean)
+    n = [int(x) for x in np.random.RandomState(1).randint(70000, 130000, size=20)]
+    for sizes in (n, [262144] * 20):
+        tasks = _plan(sizes, 8, 4096)
+        load = [sum(t[2] - t[1] for t in tasks if t[3] == w) for w in range(8)]
+        assert max(load) <= 1.05 * sum(load) / 8
+        assert sum(1 for t in tasks if t[1] == 0 and t[2] == sizes[t[0]]) >= 12, "most frames stay whole"
     # one frame, eight devices: eight runs of whole groups
     t = _plan([262144], 8, 4096)
     assert [x[2] - x[1] for x in t] == [32768] * 8 and [x[3] for x in t] == list(range(8))
+    # frames that fit are never cut
+    t = _plan([5000] * 8, 8, 4096)
+    assert all(x[1] == 0 and x[2] == 5000 for x in t) and sorted(x[3] for x in t) == list(range(8))
 
 
 def test_bench_launches_itself_for_n_gpus_dry_run():
@@ -249,6 +294,18 @@ def test_bench_launches_itself_for_n_gpus_dry_run():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["metric"].startswith("rendered rays/sec") and j["unit"] == "rays/s"
     assert abs(j["value"] - 2 * 64 * 64 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    # beside the weak headline: the product's multi-GPU path (plan, all-gather, compose) on 20 culled frames
+    ss = j["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["frames_per_step"] == 20 and ss["n_gpus"] == 2 and ss["valid_rays_per_step"] > 0
+    assert abs(ss["rays_per_s"] - ss["valid_rays_per_step"] / (ss["ms_per_step"] * 1e-3)) < 1e-6 * ss["rays_per_s"]
+    # --scaling strong: that path IS the timed region; value = rays of the whole job / max-over-ranks time
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--res", "64", "--dry-run", "--scaling", "strong", "--frames", "5"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["frames_per_step"] == 5
+    assert "strong_scaling" not in j and j["value"] > 0
     # a child failure is an error exit, not a silent empty line
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--prec", "nope", "--dry-run"],
                          capture_output=True, text=True, timeout=300, env=env)
@@ -309,3 +366,18 @@ def test_host_packer_is_clean_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
     assert "packer clean under ASan/UBSan" in run.stdout
+
+
+def test_checkpoint_discovery_follows_the_reference(tmp_path):
+    """find_checkpoint = the reload rule of create_raycaster (core/raycasters.py:124-141): ft_path wins, else the
+    last '*tar*' entry (sorted by name, 'pose' files skipped) of basedir/expname; none with no_reload."""
+    from posegen_amd.raycaster import find_checkpoint
+    d = tmp_path / "logs" / "exp"
+    d.mkdir(parents=True)
+    assert find_checkpoint(str(tmp_path / "logs"), "exp") is None
+    for name in ("050000.tar", "150000.tar", "100000.tar", "200000_pose.tar", "args.txt"):
+        (d / name).write_bytes(b"x")
+    assert find_checkpoint(str(tmp_path / "logs"), "exp") == str(d / "150000.tar")
+    assert find_checkpoint(str(tmp_path / "logs"), "exp", ft_path="None") == str(d / "150000.tar")
+    assert find_checkpoint(str(tmp_path / "logs"), "exp", ft_path="/x/y.tar") == "/x/y.tar"
+    assert find_checkpoint(str(tmp_path / "logs"), "exp", no_reload=True) is None
