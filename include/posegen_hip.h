@@ -333,6 +333,10 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
  * number of points they evaluated since the last read, and resets the counters. */
 int pg_profile_enable(pg_handle* h, int on);
 int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t* n_points);
+/* The same for the small per-ray record kernel that runs in front of every factorised 16-bit launch (what depends
+ * on the ray only -- bone-local ray, the view layer's direction part -- computed once per ray, encoders.py:25-37,
+ * cutoff_embedder.py:111-174): launches and summed device time [ms] since the last read. */
+int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms);
 
 /* Host-only (no GPU touched): pack one net's tensors (same 24-tensor order as
  * pg_load_weights) into the weight stream and bias table the kernels consume, for tests

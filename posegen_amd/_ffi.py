@@ -77,6 +77,7 @@ PROTOTYPES = {
                                      _FP, _FP, C.c_int, _FP]),
     "pg_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pg_profile_read_aux": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pg_debug_pack": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                 C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]),
     "pg_render_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -20,6 +20,8 @@
 extern "C" {
 int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream);
 int pg_launch_eval16s(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_ray_records(const pgd::RecArgs* a, int fp16, int framecode, int n_cu, void* stream);
 int pg_launch_eval16w(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
@@ -72,6 +74,7 @@ struct NetState {
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
     uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the factorised view layer
     uint8_t* d_stream_s[PG_PREC_COUNT] = {};      // 16x16x32 kernel (pg_eval16s.hip): stream, bias table
+    uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip)
     float* d_bias_s = nullptr;
     size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
@@ -95,6 +98,8 @@ struct pg_handle {
     size_t ws_bytes = 0;
     uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
     size_t fws_bytes = 0;
+    uint8_t* rec = nullptr;          // per-ray records of the factorised 16-bit path: Y [n + pad, 8 KiB] then (a, b) [n + pad, 768 B]
+    size_t rec_bytes = 0;
     // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
     // further device; every handle has a stream and a small pose buffer of its own for that path
     std::vector<pg_handle*> peers;
@@ -103,6 +108,7 @@ struct pg_handle {
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_aux;      // the record kernel in front of a factorised launch
     int64_t prof_points = 0;
 };
 
@@ -191,6 +197,55 @@ bool use_wide_waves() {
     return on;
 }
 
+// The factorised 16-bit path: pg_rayrec.hip (per-ray records) + pg_eval16r.hip (16x16x32).  POSEGEN_RECORDS=0 falls
+// back to the 32x32x16 kernel with the in-kernel table build and Y stage (A/B, debugging).
+bool use_records() {
+    static const bool on = [] { const char* e = std::getenv("POSEGEN_RECORDS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+int ensure_rec(pg_handle* h, int64_t n) {
+    const size_t need = (size_t)(n + REC_PAD_RAYS) * (REC_Y_BYTES + REC_AB_BYTES);
+    if (need <= h->rec_bytes) return PG_OK;
+    PG_HIP(h, hipSetDevice(h->device));
+    if (h->rec) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->rec)); h->rec = nullptr; h->rec_bytes = 0; }
+    const size_t want = need + need / 16;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->rec), want);
+    if (e != hipSuccess) return fail(h, PG_ENOMEM, "ray record buffer of %zu bytes failed: %s", want, hipGetErrorString(e));
+    h->rec_bytes = want;
+    // the padding rays behind the last record are fetched (never used): keep them finite
+    PG_HIP(h, hipMemset(h->rec, 0, want));
+    return PG_OK;
+}
+
+int ensure_stream_r(pg_handle* h, int which, int prec) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    PG_HIP(h, hipSetDevice(h->device));
+    if (!ns.d_stream_r[prec]) {
+        std::vector<uint8_t> packed;
+        const int rc = pgpack::pack_stream_r(t, prec, packed);
+        if (rc != 0) return fail(h, PG_EINVAL, "16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_r[prec]), packed.size()));
+        PG_HIP(h, hipMemcpy(ns.d_stream_r[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    if (!ns.d_bias_s) {
+        std::vector<float> b;
+        pgpack::pack_bias_s(t, b);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias_s), b.size() * sizeof(float)));
+        PG_HIP(h, hipMemcpy(ns.d_bias_s, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (!ns.d_vy[prec]) {
+        std::vector<uint8_t> vy;
+        if (pgpack::pack_vy(t, prec, h->cfg.framecode_ch > 0, vy) != 0)
+            return fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_vy[prec]), vy.size()));
+        PG_HIP(h, hipMemcpy(ns.d_vy[prec], vy.data(), vy.size(), hipMemcpyHostToDevice));
+    }
+    return PG_OK;
+}
+
 int ensure_stream_s(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (ns.d_stream_s[prec]) return PG_OK;
@@ -233,6 +288,10 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
 
 // the packed weight streams a precision mode will use for net `which`, built ahead of the first render
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
+    if (is_shape_a(mode) && use_records() && use_fact(mode, FACT_MIN_S)) {
+        const int rc = ensure_stream_r(h, which, mode);
+        return rc ? rc : ensure_stream(h, which, mode, false);        // + the direct kernel's stream (short rays, points)
+    }
     if (mode != PG_PREC_FP16M) return ensure_stream(h, which, mode, use_fact(mode, FACT_MIN_S));
     int rc = ensure_stream(h, which, PG_PREC_FP16C, use_fact(PG_PREC_FP16C, FACT_MIN_S));
     if (!rc && which == 0) rc = ensure_stream(h, which, PG_PREC_FP16, use_fact(PG_PREC_FP16, FACT_MIN_S));
@@ -267,10 +326,12 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     // explicit points and position noise need q = R p + t per point: the direct kernels (no per-ray a + z b table)
     const bool compk = !pnoise && use_comp_kernel(prec, S, points != nullptr);
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
-    int rc = ensure_stream(h, which, prec, fact);
-    if (rc) return rc;
     const bool sa = is_shape_a(prec);
-    const bool small = sa && fact && use_small_tiles();           // the opt-in variants exist for bf16 / fp16 only
+    const bool recs = sa && fact && use_records();                // per-ray records + the 16x16x32 kernel
+    int rc = recs ? ensure_stream_r(h, which, prec) : ensure_stream(h, which, prec, fact);
+    if (rc) return rc;
+    if (recs && (rc = ensure_rec(h, n))) return rc;
+    const bool small = sa && fact && !recs && use_small_tiles();  // the opt-in variants exist for bf16 / fp16 only
     if (small && (rc = ensure_stream_s(h, which, prec))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
@@ -278,9 +339,13 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
+    a.wstream = recs ? ns.d_stream_r[prec] : small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
     a.wy = (fact && !compk) ? ns.d_vy[prec] : nullptr;
-    a.bias = small ? ns.d_bias_s : ns.d_bias;
+    a.bias = (small || recs) ? ns.d_bias_s : ns.d_bias;
+    if (recs) {
+        a.rec_y = h->rec;
+        a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES);
+    }
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
     a.pose_stride = pose_stride;
@@ -303,16 +368,28 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     if (wg_cap > 0 && wg_cap < max_wg) max_wg = wg_cap;
     const int grid = (int)(iters < max_wg ? iters : max_wg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto get = [&](hipEvent_t& ev) {
+        if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); return hipSuccess; }
+        return hipEventCreate(&ev);
+    };
+    if (recs) {     // what depends on the ray only, once per ray, in front of the fused kernel (pg_rayrec.hip)
+        pgd::RecArgs ra{};
+        ra.rays = rays; ra.skts = skts; ra.cams = cams; ra.codes = a.codes; ra.wy = a.wy;
+        ra.rec_ab = const_cast<float*>(a.rec_ab); ra.rec_y = const_cast<uint8_t*>(a.rec_y);
+        ra.pose_stride = pose_stride; ra.n_rays = (int)n; ra.n_codes = ns.n_codes;
+        hipEvent_t x0 = nullptr, x1 = nullptr;
+        if (h->profiling) { PG_HIP(h, get(x0)); PG_HIP(h, get(x1)); PG_HIP(h, hipEventRecord(x0, static_cast<hipStream_t>(stream))); }
+        const int er = pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);
+        if (h->profiling) { PG_HIP(h, hipEventRecord(x1, static_cast<hipStream_t>(stream))); h->ev_aux.emplace_back(x0, x1); }
+        if (er) return fail(h, PG_EHIP, "ray record kernel launch failed: %s", hipGetErrorString((hipError_t)er));
+    }
     if (h->profiling) {
-        auto get = [&](hipEvent_t& ev) {
-            if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); return hipSuccess; }
-            return hipEventCreate(&ev);
-        };
         PG_HIP(h, get(e0));
         PG_HIP(h, get(e1));
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
-    int e = small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
+    int e = recs ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, grid, stream)
+          : small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : (sa && fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
           : compk ? pg_launch_evalc(&a, fc, grid, stream)
@@ -422,7 +499,10 @@ void pg_destroy(pg_handle* h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->d_pose) (void)hipFree(h->d_pose);
     if (h->fws) (void)hipFree(h->fws);
+    if (h->rec) (void)hipFree(h->rec);
+    for (auto& pr : h->ev_aux) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (NetState& ns : h->net) {
+        for (auto& p : ns.d_stream_r) if (p) (void)hipFree(p);
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         for (auto& p : ns.d_stream_s) if (p) (void)hipFree(p);
@@ -468,6 +548,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     for (int p = 0; p < PG_PREC_COUNT; ++p) {
         if (ns.d_vy[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vy[p])); ns.d_vy[p] = nullptr; }
         if (ns.d_stream_s[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_s[p])); ns.d_stream_s[p] = nullptr; }
+        if (ns.d_stream_r[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_r[p])); ns.d_stream_r[p] = nullptr; }
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
     std::vector<float> bias;
@@ -537,6 +618,24 @@ int pg_set_chunk(pg_handle* h, int chunk) {
 int pg_profile_enable(pg_handle* h, int on) {
     if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_enable: null handle");
     h->profiling = on != 0;
+    return PG_OK;
+}
+
+int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms) {
+    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_read_aux: null handle");
+    PG_HIP(h, hipSetDevice(h->device));
+    double ms = 0.0;
+    for (auto& pr : h->ev_aux) {
+        PG_HIP(h, hipEventSynchronize(pr.second));
+        float t = 0.f;
+        PG_HIP(h, hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        h->ev_free.push_back(pr.first);
+        h->ev_free.push_back(pr.second);
+    }
+    if (n_launches) *n_launches = (int64_t)h->ev_aux.size();
+    if (total_ms) *total_ms = ms;
+    h->ev_aux.clear();
     return PG_OK;
 }
 
@@ -662,6 +761,11 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     // 16-bit kernels: the factorised-view program (rays with >= 64 samples, the usual case)
     const bool fact = use_fact(precision, FACT_MIN_S);
     const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
+    if (sa && fact && use_records()) {      // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
+        if (stream_bytes) *stream_bytes = (int64_t)pgp::R::NCHUNK * CHUNK_BYTES;
+        if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
+        return PG_OK;
+    }
     if (stream_bytes)
         *stream_bytes = (int64_t)(compk ? pgp::C::NCHUNK : sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK)
                                      : (precision == PG_PREC_FP32 ? pgp::B::NCHUNK : pgp::B::NCHUNK_FOLD)) * CHUNK_BYTES;

@@ -24,6 +24,8 @@ struct EvalArgs {
     const float* codes;       // [n_codes+1,16], last row = mean code; null if no frame code
     const uint8_t* wstream;   // packed weights (pg_pack.cpp)
     const uint8_t* wy;        // Y-stage weights of the factorised view layer (pack_vy), or null
+    const float* rec_ab;      // per-ray records (pg_rayrec.hip) of the 16x16x32 kernel, or null
+    const uint8_t* rec_y;
     const float* bias;        // BIAS_FLOATS
     const float* cutoff;      // [48] = cutoff_dist of embed_fn (24) then embeddirs_fn (24)
     float* raw;               // [n*S,4] (rgb_raw, sigma_raw)
@@ -36,6 +38,20 @@ struct EvalArgs {
     int n_iters;              // workgroup passes = ceil(n_points / points per pass)
     float tau_v, tau_d;
     int dbg_stage;            // which activation `dbg` receives (see pg_stage_eval)
+};
+
+// Kernel arguments of the per-ray record kernel (pg_rayrec.hip) in front of a factorised 16-bit launch.
+struct RecArgs {
+    const float* rays;        // [n,11]
+    const float* skts;        // [*,24,4,4]
+    const float* cams;        // [n] or null
+    const float* codes;       // [n_codes+1,16] or null
+    const uint8_t* wy;        // Y-stage weights (pack_vy)
+    float* rec_ab;            // [n + REC_PAD_RAYS][24][8]
+    uint8_t* rec_y;           // [n + REC_PAD_RAYS][REC_Y_BYTES]
+    long long pose_stride;
+    int n_rays;
+    int n_codes;
 };
 
 // The opt-in to > 64 KiB of dynamic LDS is per (kernel, device): set once per device, from any host

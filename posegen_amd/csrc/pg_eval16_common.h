@@ -145,9 +145,24 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
     if (PG_SPREAD_DMA) {
         // refill piece i of the freed slot goes out at unit i*PSTRIDE+PG_DMA_PHASE of this
         // chunk; a segment ending inside the chunk flushes the rest with its last unit
+#if defined(PG_DMA_STAGGER)
+        // the two waves of a SIMD run the same program a few cycles apart: with one phase both stall in the issue
+        // of a refill piece at the same time and the matrix pipe idles; waves NWAVE/2.. issue half a stride later
+        constexpr int PH2 = (PG_DMA_PHASE + PSTRIDE / 2) % PSTRIDE;
+        if (st.wave < NWAVE / 2) {
+            if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
+            if (L == T - 1)
+                for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
+        } else {
+            if (q % PSTRIDE == PH2) st.piece(q / PSTRIDE);
+            if (L == T - 1)
+                for (int i = (q < PH2 ? 0 : (q - PH2) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
+        }
+#else
         if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
         if (L == T - 1)
             for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
+#endif
     }
     if (PG_EARLY_RETIRE) {
         // The retire "writes" its register as far as hipcc knows, and a VALU write directly
@@ -158,6 +173,36 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
     } else {
         lds_retire(p.r[L % NS], min(LA, rem));
     }
+    return __builtin_bit_cast(V, p.r[L % NS]);
+}
+
+// An LDS read that runs BESIDE the weight-ring pipe (a bias tile, the (a, b) rows of the next joint): issued by inline
+// asm like the ring reads, because a read hipcc can see makes it wait `lgkmcnt(0)` in front of the consumer -- it does
+// not count the hand-issued ring reads, so that wait drains the A pipe (every tile boundary and every joint of the
+// embedding exposed a full LDS latency that way).  LDS operations return in order: issued in front of next_a(L)'s own
+// issue, the read has landed once next_a(L + 1) has retired its unit (that wait leaves only the LA youngest ring reads
+// outstanding), so it needs no wait of its own -- only lds_landed() behind such a retire as the point hipcc may
+// read the register from (asm volatile statements keep their order).
+__device__ __forceinline__ void lds_async128(a128& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:0+0" : "=v"(dst) : "v"(lds_addr));
+}
+__device__ __forceinline__ void lds_landed(a128& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// Units of a segment that CONTINUES a chunk already entered and whose refill pieces are all out (the rgb head behind
+// the alpha / view segment): positions Q0 .. Q0+T-1 of the current chunk, no chunk entry, no refill pieces.
+template <typename V, int T, int NS, int Q0, typename ST>
+__device__ __forceinline__ V next_a_cont(APipe<V, NS>& p, ST& st, int L) {
+    static_assert(Q0 + T <= UPC, "a continuation stays inside its chunk");
+    constexpr int LA = NS - 1;
+    const int q = Q0 + L, rem = T - 1 - L;
+    if (L == 0)
+        for (int k = 0; k < LA; ++k)
+            if (k <= rem) st.issue(p.r[(L + k) % NS], q + k);
+    if (LA <= rem) st.issue(p.r[(L + LA) % NS], q + LA);
+    lds_retire(p.r[L % NS], min(LA, rem));
     return __builtin_bit_cast(V, p.r[L % NS]);
 }
 

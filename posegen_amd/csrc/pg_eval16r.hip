@@ -1,0 +1,502 @@
+// pg_eval16r.hip -- fused bone-relative embedding + NeRF MLP on v_mfma_f32_16x16x32 (bf16 / fp16 operands, fp32
+// accumulate) for rays with >= 64 samples: the kernel behind PG_PREC_BF16 / PG_PREC_FP16 renders.
+//
+// Replaces RayCaster.encode_inputs + run_network + NeRF.forward for one net (reference core/raycasters.py:476-577,
+// core/networks/nerf.py:90-148, core/encoders.py, core/cutoff_embedder.py) on n*S points p = o + d*z.
+//
+// Structure (pg_layout.h "small tile"): 8 waves x 32 points per workgroup pass, a wave keeps the activations of its
+// points in registers through all layers; A = 16 out channels x 32 k (weights, streamed L2 -> LDS ring by LDS-DMA and
+// shared by all waves), B = 32 k x 16 points; a wave's 32 points are two column tiles, so every A fragment read
+// from the ring feeds two MFMAs; lane group g = lane>>4 generates the density embedding of joints 6g..6g+5 for the
+// wave's points col and col+16 on the fly (never stored; regenerated for the skip layer).
+//
+// Two things set it apart from its 32x32x16 predecessor (pg_eval16.hip, now the direct-view kernel for short rays,
+// explicit points and position noise):
+//   * the MFMA shape: MI355X holds a ~15 % higher clock on 16x16x32 at equal cycles per FLOP (measured on this
+//     pool: 2.15 vs 1.86 PFLOP/s sustained with LDS-fed operands; MI355X_MICROARCH.md, DVFS give-back 7) -- the
+//     kernel is power-limited (all-zero weights run the same instruction stream 19 % faster), so this is the lever;
+//   * everything that depends on the RAY only -- the bone-local ray (a_j, b_j) and the view layer's direction part
+//     Y[ray][j] -- arrives as per-ray records computed by pg_rayrec.hip and is fetched with a few LDS-DMA pieces per
+//     pass: no table build, no Y stage, no extra barriers and no Y-stage weight traffic at the pass boundary (13 %
+//     of a pass before), and the rgb head shares the last chunk of the alpha / view segment (one chunk entry less).
+#ifndef PG_PREFETCH
+#define PG_PREFETCH 1
+#endif
+#include "pg_eval16_common.h"
+
+namespace pgd {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename V> struct Op16;
+template <> struct Op16<bf16x8> {
+    static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Op16<f16x8> {
+    static __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES>;
+
+// LDS carve-up of this kernel (bytes)
+constexpr int LDSR_RING = 0;
+constexpr int LDSR_BIAS = PG_RING_SLOTS * CHUNK_BYTES;          // BIAS16_FLOATS floats
+constexpr int LDSR_CUT = LDSR_BIAS + BIAS16_FLOATS * 4;         // 48 floats
+constexpr int LDSR_AB = LDSR_CUT + 48 * 4;                      // two buffers of LDS_AB_BYTES: this pass / the next
+constexpr int LDSR_Y = LDSR_AB + 2 * LDS_AB_BYTES;              // MAXR_F rays x REC_Y_BYTES
+constexpr int LDSR_TOTAL = LDSR_Y + MAXR_F * REC_Y_BYTES;
+static_assert(LDSR_BIAS % 16 == 0 && LDSR_CUT % 16 == 0 && LDSR_AB % 16 == 0 && LDSR_Y % 16 == 0, "LDS alignment");
+static_assert(LDSR_TOTAL <= 160 * 1024, "LDS budget of one CU");
+
+__device__ __forceinline__ f32x4 load_bias16(const float* bias, int tile, int g) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + tile * 16 + 4 * g);
+    f32x4 r = {b.x, b.y, b.z, b.w};
+    return r;
+}
+
+// out tiles 2u (lo) and 2u+1 (hi) of one column tile -> k-unit u of the next layer
+template <typename V>
+__device__ __forceinline__ V relu_pack16(const f32x4& lo, const f32x4& hi, bool relu) {
+    const float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    V f = Op<V>::cvt(t);
+    return relu ? relu16<V>(f) : f;
+}
+
+// one LDS-DMA piece (1 KiB, lane-linear) from a wave-uniform source to a wave-uniform LDS address; counted by the
+// chunk entries' vmcnt like the ring's own pieces (in-order completion: anything issued before a chunk's refill
+// pieces has landed by the next entry, and is visible to every wave behind that entry's barrier)
+__device__ __forceinline__ void dma_piece(const uint8_t* src, uint32_t lds_dst, uint32_t lane16) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane16), "s"(src) : "memory");
+}
+
+// one k-unit (two B fragments, one per column tile) against NO out tiles of a k-major segment
+template <typename V, int NO, int T, int NS, typename ST>
+__device__ __forceinline__ void mma_row16(f32x4 (*acc)[2], APipe<V, NS>& p, ST& st, int uu, V b0, V b1) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const V av = next_a<V, T, true, NS>(p, st, uu * NO + o);
+        acc[o][0] = Op16<V>::mfma(av, b0, acc[o][0]);
+        acc[o][1] = Op16<V>::mfma(av, b1, acc[o][1]);
+    }
+}
+
+// acc += W[:, x-columns] x for the wave's two column tiles; X16 sequence of pg_layout.h: joints 0..3 (two units
+// each), their leftovers, joints 4, 5, their leftovers.  `ab0` / `ab1`: LDS byte address of the (a, b) row of the lane
+// group's first joint for the two points; the rows of joint jj + 1 are fetched beside the ring pipe (lds_async128)
+// while joint jj is multiplied.  `hook` runs once behind the first unit row, i.e. behind the segment's first chunk
+// entry (the per-pass record fetch of layer 0 hangs there).
+template <typename V, typename ST, typename HOOK>
+__device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float* abp0, const float* abp1, float z0, float z1,
+                                            const float* cutv, float tau, HOOK hook) {
+    APipeX<V> p;
+    constexpr int T = XU16 * NT16;
+    float lo0[8], lo1[8];
+    int uu = 0;
+#if PG_R_ASYNC_AB
+    const unsigned ab0 = lds_addr_of(abp0), ab1 = lds_addr_of(abp1);
+    a128 ab[2][4];          // [joint parity][point 0 lo, hi, point 1 lo, hi]: (a, pad) and (b, pad)
+    auto fetch = [&](int jj) {
+        lds_async128(ab[jj & 1][0], ab0 + jj * 32);
+        lds_async128(ab[jj & 1][1], ab0 + jj * 32 + 16);
+        lds_async128(ab[jj & 1][2], ab1 + jj * 32);
+        lds_async128(ab[jj & 1][3], ab1 + jj * 32 + 16);
+    };
+    fetch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the ring pipe is empty between segments
+#else
+    const QFromAB q0{abp0, z0}, q1{abp1, z1};
+#endif
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < JG; ++jj) {
+        float x0[18], x1[18];
+#if PG_R_ASYNC_AB
+        if (jj + 1 < JG) fetch(jj + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_landed(ab[jj & 1][k]);
+        {
+            const float4 lo = __builtin_bit_cast(float4, ab[jj & 1][0]), hi = __builtin_bit_cast(float4, ab[jj & 1][1]);
+            joint_values_q<true>(fmaf(z0, hi.x, lo.x), fmaf(z0, hi.y, lo.y), fmaf(z0, hi.z, lo.z), tau, cutv[jj], x0);
+        }
+        {
+            const float4 lo = __builtin_bit_cast(float4, ab[jj & 1][2]), hi = __builtin_bit_cast(float4, ab[jj & 1][3]);
+            joint_values_q<true>(fmaf(z1, hi.x, lo.x), fmaf(z1, hi.y, lo.y), fmaf(z1, hi.z, lo.z), tau, cutv[jj], x1);
+        }
+#else
+        float qx, qy, qz;
+        q0(jj, qx, qy, qz);
+        joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x0);
+        q1(jj, qx, qy, qz);
+        joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x1);
+#endif
+        const int k = jj < 4 ? jj : jj - 4;
+        lo0[2 * k] = x0[16]; lo0[2 * k + 1] = x0[17];
+        lo1[2 * k] = x1[16]; lo1[2 * k + 1] = x1[17];
+        mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0), Op<V>::cvt(x1));
+        if (jj == 0) hook();
+        mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0 + 8), Op<V>::cvt(x1 + 8));
+        if (jj == 3 || jj == JG - 1) {
+            if (jj == JG - 1) {
+#pragma unroll
+                for (int e = 4; e < 8; ++e) { lo0[e] = 0.0f; lo1[e] = 0.0f; }
+            }
+            mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(lo0), Op<V>::cvt(lo1));
+        }
+    }
+}
+
+// The bias tile of the next out tile, fetched beside the ring pipe: fetch() in front of a next_a() whose successor
+// still runs before take() (then the read has landed, see lds_async128); take() behind a next_a().  The tile index
+// goes into the instruction's offset field and the base is made opaque per layer: with the addresses visible hipcc
+// computes all 138 of them ahead of the pass loop and spills them (a scratch reload per tile, each waiting vmcnt(0)).
+struct BiasPipe {
+    unsigned base;          // LDS byte address of the lane group's rows of the segment's first bias tile
+    a128 r;
+    __device__ __forceinline__ BiasPipe(unsigned bbase, int tile0) : base(bbase + tile0 * 64) { asm volatile("" : "+v"(base)); }
+    __device__ __forceinline__ void fetch(int k) {          // tile0 + k, k < 16 (constant after unrolling)
+        switch (k) {
+#define PG_BIAS_CASE(K) case K: asm volatile("ds_read_b128 %0, %1 offset:0+" #K "*64" : "=v"(r) : "v"(base)); break;
+            PG_BIAS_CASE(0) PG_BIAS_CASE(1) PG_BIAS_CASE(2) PG_BIAS_CASE(3) PG_BIAS_CASE(4) PG_BIAS_CASE(5) PG_BIAS_CASE(6) PG_BIAS_CASE(7)
+            PG_BIAS_CASE(8) PG_BIAS_CASE(9) PG_BIAS_CASE(10) PG_BIAS_CASE(11) PG_BIAS_CASE(12) PG_BIAS_CASE(13) PG_BIAS_CASE(14) PG_BIAS_CASE(15)
+#undef PG_BIAS_CASE
+            default: __builtin_unreachable();
+        }
+    }
+    __device__ __forceinline__ f32x4 take() { lds_landed(r); return __builtin_bit_cast(f32x4, r); }
+};
+
+// one out tile of an out-tile-major segment of T units on the activation fin[HU16][2]
+template <typename V, int T, int NS, typename ST>
+__device__ __forceinline__ void row_tile16(f32x4& acc0, f32x4& acc1, APipe<V, NS>& p, ST& st, int o, const V (*fin)[2]) {
+#pragma unroll
+    for (int u = 0; u < HU16; ++u) {
+        const V av = next_a<V, T, true, NS>(p, st, o * HU16 + u);
+        acc0 = Op16<V>::mfma(av, fin[u][0], acc0);
+        acc1 = Op16<V>::mfma(av, fin[u][1], acc1);
+    }
+}
+
+#ifndef PG_R_ASYNC_AB
+#define PG_R_ASYNC_AB 0       // (a, b) rows of the next joint fetched beside the ring pipe (16 more live registers)
+#endif
+#ifndef PG_R_PACK_AT
+#define PG_R_PACK_AT 2        // unit of an even tile behind which the previous tile pair is converted
+#endif
+#ifndef PG_R_BIAS_AT
+#define PG_R_BIAS_AT 4        // unit behind which the next tile's bias is fetched (>= 2 units before the tile ends)
+#endif
+static_assert(PG_R_BIAS_AT <= HU16 - 3, "the bias fetch needs two more retires of the tile behind it");
+// fout = relu(W fin + b): 16 out tiles of 16 channels, out-tile-major.  The ReLU + 16-bit packing of a finished
+// tile pair (VALU, needs the pair's last MFMA to retire) is placed behind the first MFMAs of the next tile, and the
+// next tile's bias is read mid-tile, so that neither sits at a tile boundary where the matrix pipe would drain.
+template <typename V, typename ST>
+__device__ __forceinline__ void hidden_layer16(const V (*fin)[2], V (*fout)[2], ST& st, unsigned bbase, int tile0) {
+    APipe<V> p;
+    constexpr int T = HU16 * NT16;
+    f32x4 lo0, lo1, hi0, hi1;
+    BiasPipe bp(bbase, tile0);
+    bp.fetch(0);
+#pragma unroll
+    for (int o = 0; o < NT16; ++o) {
+        f32x4 acc0, acc1;
+#pragma unroll
+        for (int u = 0; u < HU16; ++u) {
+            const V av = next_a<V, T, true, PG_PIPE_H>(p, st, o * HU16 + u);
+            if (u == 0) acc0 = acc1 = bp.take();
+            acc0 = Op16<V>::mfma(av, fin[u][0], acc0);
+            acc1 = Op16<V>::mfma(av, fin[u][1], acc1);
+            if (u == PG_R_PACK_AT && o >= 2 && (o & 1) == 0) {
+                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
+                fout[o / 2 - 1][0] = relu_pack16<V>(lo0, hi0, true);
+                fout[o / 2 - 1][1] = relu_pack16<V>(lo1, hi1, true);
+                if (PG_PIN_TILE) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (u == PG_R_BIAS_AT && o + 1 < NT16) bp.fetch(o + 1);     // in front of the next unit's next_a
+        }
+        if (o & 1) { hi0 = acc0; hi1 = acc1; } else { lo0 = acc0; lo1 = acc1; }
+    }
+    fout[NT16 / 2 - 1][0] = relu_pack16<V>(lo0, hi0, true);
+    fout[NT16 / 2 - 1][1] = relu_pack16<V>(lo1, hi1, true);
+}
+
+// second stage of the factorised view layer: vacc[t][c] += sum_j w_j Y[ray][j][16t..] for the (at most two) rays
+// of the wave; Y[ray] = the ray's record as fetched into LDS (A fragments: [out tile16][lane (g, row)] x 16 B)
+template <typename V, bool FC>
+__device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds, const float (*wd)[JG],
+                                          const int* myr, int lane) {
+    const int g = lane >> 4;
+    u32x4 w[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float wx[8];
+#pragma unroll
+        for (int e = 0; e < JG; ++e) wx[e] = wd[c][e];
+        wx[6] = (FC && g == 0) ? 1.0f : 0.0f;
+        wx[7] = 0.0f;
+        w[c] = __builtin_bit_cast(u32x4, Op<V>::cvt(wx));
+    }
+    const int ra = __builtin_amdgcn_readfirstlane(myr[0]);
+    const int rb = __builtin_amdgcn_readlane(myr[1], 63);
+    for (int ray = ra; ray <= rb; ++ray) {
+        u32x4 b0, b1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { b0[q] = myr[0] == ray ? w[0][q] : 0u; b1[q] = myr[1] == ray ? w[1][q] : 0u; }
+        const uint8_t* yb = ylds + ray * REC_Y_BYTES + lane * 16;
+#pragma unroll
+        for (int t = 0; t < NTV16; ++t) {
+            const V av = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + t * 1024));
+            vacc[t][0] = Op16<V>::mfma(av, __builtin_bit_cast(V, b0), vacc[t][0]);
+            vacc[t][1] = Op16<V>::mfma(av, __builtin_bit_cast(V, b1), vacc[t][1]);
+        }
+    }
+}
+
+// TAPS = the debug tap of pg_stage_eval (stage 0: pre-activation of density layer 0) compiled in: its own
+// instantiation, launched only when a dump is asked for
+template <typename V, bool FC, bool TAPS>
+__global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* bias = reinterpret_cast<float*>(smem + LDSR_BIAS);
+    float* cut = reinterpret_cast<float*>(smem + LDSR_CUT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    StreamR st{a.wstream, smem + LDSR_RING, wave, lane, 0u, 0u, 0u, lds0 + LDSR_RING, lane16};
+    const uint8_t* rec_ab = reinterpret_cast<const uint8_t*>(a.rec_ab);
+
+    for (int i = tid; i < BIAS16_FLOATS; i += NTHR) bias[i] = a.bias[i];
+    const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
+    if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    st.start();
+    const unsigned bbase = lds_addr_of(bias) + 16 * g;          // this lane group's rows of bias tile 0
+    // Ray bookkeeping without a division per pass (a 64-bit divide is ~150 VALU instructions, and both waves of a
+    // SIMD would run it at the same time): the pass's first point is sample `off0` of ray `r0`; a pass later both
+    // advance by the constant step of the persistent grid.
+    const long long step = (long long)PTS * gridDim.x;
+    const int dq = __builtin_amdgcn_readfirstlane((int)(step / a.S)), dr = __builtin_amdgcn_readfirstlane((int)(step % a.S));
+    long long p0 = (long long)blockIdx.x * PTS;
+    int r0 = __builtin_amdgcn_readfirstlane((int)(p0 / a.S));
+    int off0 = __builtin_amdgcn_readfirstlane((int)(p0 - (long long)r0 * a.S));
+    // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched a pass ahead
+    if ((int)blockIdx.x < a.n_iters && wave < LDS_AB_BYTES / 1024)
+        dma_piece(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSR_AB + wave * 1024, lane16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    int abuf = 0;
+
+    // depths of the next pass, fetched a pass ahead (consumed at the top of the pass: one wait finds them there)
+    float nx_z[2] = {0.0f, 0.0f};
+#define PG_PREFETCH_Z(itn)                                                                         \
+    do {                                                                                           \
+        const long long p0n_ = (long long)(itn) * PTS + wave * 32 + col;                           \
+        nx_z[0] = a.z[min(p0n_, a.n_points - 1)];                                                  \
+        nx_z[1] = a.z[min(p0n_ + 16, a.n_points - 1)];                                             \
+    } while (0)
+    if ((int)blockIdx.x < a.n_iters) PG_PREFETCH_Z(blockIdx.x);
+
+#if defined(PG_STAMPS)
+    unsigned long long stamps[12];
+#endif
+    for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
+        PG_STAMP(0);
+        // rays of the pass's points: point i of the pass is sample off0 + i of ray r0, i.e. (S >= 64, 256 points)
+        // at most 4 rays on; points past the end of the launch (last pass) take the last valid ray
+        const int last = (int)min((long long)PTS - 1, a.n_points - 1 - p0);                 // wave-uniform
+        const int S1 = a.S, S2 = 2 * a.S, S3 = 3 * a.S, S4 = 4 * a.S;
+        auto ray_of = [&](int t) { return (t >= S1) + (t >= S2) + (t >= S3) + (t >= S4); };
+        const int nrm1 = ray_of(off0 + last);
+        int myr[2];
+        float zz[2];
+        const float* abp[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int i = wave * 32 + 16 * c + col;
+            myr[c] = min(ray_of(off0 + i), nrm1);
+            zz[c] = nx_z[c];
+            abp[c] = opaque_ptr(reinterpret_cast<const float*>(smem + LDSR_AB + abuf * LDS_AB_BYTES + myr[c] * REC_AB_BYTES) + JG * g * 8);
+        }
+        // the next pass of this workgroup
+        const int itn = min(it + (int)gridDim.x, a.n_iters - 1);
+        int off0n = off0 + dr, r0n = r0 + dq;
+        if (off0n >= a.S) { off0n -= a.S; ++r0n; }
+        const float* cutd = opaque_ptr(cut + J + JG * g);
+        const QFromAB q0{abp[0], zz[0]}, q1{abp[1], zz[1]};
+        float cutv[JG];                         // the lane group's folded cutoff constants (6 registers)
+#pragma unroll
+        for (int jj = 0; jj < JG; ++jj) cutv[jj] = cut[JG * g + jj];
+        // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the
+        // (a, b) buffer of the pass before may be overwritten.  Wave w fetches out tile w of this pass's MAXR_F Y
+        // records and waves 0..3 a piece of the NEXT pass's (a, b); both are in LDS, and visible, one chunk entry on.
+        auto fetch_records = [&]() {
+            const uint8_t* ysrc = a.rec_y + (size_t)r0 * REC_Y_BYTES + wave * 1024;
+#pragma unroll
+            for (int k = 0; k < MAXR_F; ++k) dma_piece(ysrc + (size_t)k * REC_Y_BYTES, lds0 + LDSR_Y + k * REC_Y_BYTES + wave * 1024, lane16);
+            if (wave < LDS_AB_BYTES / 1024)
+                dma_piece(rec_ab + (long long)min(r0n, a.n_rays - 1) * REC_AB_BYTES + wave * 1024,
+                          lds0 + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES + wave * 1024, lane16);
+        };
+
+        PG_STAMP(1);
+        V fa[HU16][2], fb[HU16][2];
+        {   // ---- layer 0: K = 432 generated on the fly, all 16 out tiles live ----
+            f32x4 acc[NT16][2];
+#pragma unroll
+            for (int o = 0; o < NT16; ++o) acc[o][0] = acc[o][1] = load_bias16(bias, BS_LAYER0 + o, g);
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, fetch_records);
+            if (TAPS && a.dbg && a.dbg_stage == 0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int i = wave * 32 + 16 * c + col;
+                    if (i <= last) {
+#pragma unroll
+                        for (int o = 0; o < NT16; ++o)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a.dbg[(p0 + i) * W + 16 * o + 4 * g + r] = acc[o][c][r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < HU16; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fa[u][c] = relu_pack16<V>(acc[2 * u][c], acc[2 * u + 1][c], true);
+        }
+        PG_STAMP(2);
+        // ---- layers 1..4 ----
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 1 * NT16);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 2 * NT16);
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 3 * NT16);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 4 * NT16);
+        PG_STAMP(3);
+        {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
+            f32x4 acc[NT16][2];
+            APipeX<V> p5;
+            BiasPipe bp(bbase, BS_LAYER0 + 5 * NT16);
+            bp.fetch(0);
+#pragma unroll
+            for (int o = 0; o < NT16; ++o) {
+#pragma unroll
+                for (int u = 0; u < HU16; ++u) {
+                    const V av = next_a<V, HU16 * NT16, true, PG_PIPE_X>(p5, st, o * HU16 + u);
+                    if (u == 0) acc[o][0] = acc[o][1] = bp.take();
+                    acc[o][0] = Op16<V>::mfma(av, fa[u][0], acc[o][0]);
+                    acc[o][1] = Op16<V>::mfma(av, fa[u][1], acc[o][1]);
+                    if (u == PG_R_BIAS_AT && o + 1 < NT16) bp.fetch(o + 1);
+                }
+            }
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, [] {});
+#pragma unroll
+            for (int u = 0; u < HU16; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fb[u][c] = relu_pack16<V>(acc[2 * u][c], acc[2 * u + 1][c], true);
+        }
+        PG_STAMP(4);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 6 * NT16);
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 7 * NT16);
+        PG_STAMP(5);
+        // ---- sigma head + view layer (feature layer folded in, view directions from the Y records) + rgb head,
+        // one stream segment: the rgb head's 4 units sit in the chunk the view tiles end in ----
+        float sigma[2];
+        V fg[NTV16 / 2][2];
+        APipe<V> pv;
+        {
+            f32x4 vacc[NTV16][2];
+            constexpr int TAV = pgp::R::U_AV;
+            static_assert(BS_VIEWF == BS_ALPHA + 1 && BS_RGB == BS_VIEWF + NTV16, "alpha, view and rgb bias tiles are consecutive");
+            BiasPipe bp(bbase, BS_ALPHA);
+            bp.fetch(0);
+#pragma unroll
+            for (int o = 0; o < NTV16 + 1; ++o) {       // tile 0: alpha (row 0), tiles 1..8: the folded view layer
+                f32x4 t0, t1;
+#pragma unroll
+                for (int u = 0; u < HU16; ++u) {
+                    const V av = next_a<V, TAV, true, PG_PIPE_H>(pv, st, o * HU16 + u);
+                    if (u == 0) t0 = t1 = bp.take();
+                    t0 = Op16<V>::mfma(av, fb[u][0], t0);
+                    t1 = Op16<V>::mfma(av, fb[u][1], t1);
+                    if (u == PG_R_BIAS_AT && o < NTV16) bp.fetch(o + 1);
+                }
+                if (o == 0) { sigma[0] = t0[0]; sigma[1] = t1[0]; }
+                else { vacc[o - 1][0] = t0; vacc[o - 1][1] = t1; }
+            }
+            PG_STAMP(6);
+            float wd[2][JG];
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                float qx, qy, qz;
+                q0(jj, qx, qy, qz);
+                wd[0][jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+                q1(jj, qx, qy, qz);
+                wd[1][jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+            }
+            y_apply16<V, FC>(vacc, smem + LDSR_Y, wd, myr, lane);
+#pragma unroll
+            for (int u = 0; u < NTV16 / 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fg[u][c] = relu_pack16<V>(vacc[2 * u][c], vacc[2 * u + 1][c], true);
+        }
+        PG_STAMP(7);
+        // the next pass's depths: in flight through the rgb head and the pass boundary (unconditional: a
+        // conditional re-definition would keep registers live through the whole pass)
+        PG_PREFETCH_Z(itn);
+        f32x4 c0, c1;
+        {
+            APipe<V> pr;
+            BiasPipe bp(bbase, BS_RGB);
+            bp.fetch(0);
+#pragma unroll
+            for (int u = 0; u < pgp::R::U_RGB; ++u) {
+                const V av = next_a_cont<V, pgp::R::U_RGB, PG_PIPE_H, pgp::R::U_AV % UPC>(pr, st, u);
+                if (u == 0) c0 = c1 = bp.take();
+                c0 = Op16<V>::mfma(av, fg[u][0], c0);
+                c1 = Op16<V>::mfma(av, fg[u][1], c1);
+            }
+        }
+        if (g == 0) {       // rows 0..2 of the rgb tile and row 0 of the alpha tile live in lane group 0
+            const int i = wave * 32 + col;      // (the pass's point index is recomputed here rather than kept for the whole pass)
+            if (i <= last) *reinterpret_cast<float4*>(a.raw + (p0 + i) * 4) = make_float4(c0[0], c0[1], c0[2], sigma[0]);
+            if (i + 16 <= last) *reinterpret_cast<float4*>(a.raw + (p0 + i + 16) * 4) = make_float4(c1[0], c1[1], c1[2], sigma[1]);
+        }
+        abuf ^= 1;
+        p0 += step; r0 = r0n; off0 = off0n;
+        PG_STAMP(8);
+#if defined(PG_STAMPS)
+        if (a.dbg && a.dbg_stage == 99 && lane == 0 && it < 64) {
+            for (int k = 0; k < 9; ++k) reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + k] = stamps[k];
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + 9] = st.t_vm;
+            reinterpret_cast<unsigned long long*>(a.dbg)[((long long)it * NWAVE + wave) * 16 + 10] = st.t_bar;
+            st.t_vm = 0; st.t_bar = 0;
+        }
+#endif
+    }
+    st.drain();
+}
+
+template <typename V, bool FC, bool TAPS>
+static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream) {
+    auto k = eval16r_kernel<V, FC, TAPS>;
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDSR_TOTAL, attr_done);
+    if (ae != hipSuccess) return ae;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDSR_TOTAL, stream, a);
+    return hipGetLastError();
+}
+
+template <typename V>
+static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int grid, hipStream_t s) {
+    if (a.dbg && a.dbg_stage != 99) return framecode ? launch_eval16r<V, true, true>(a, grid, s) : launch_eval16r<V, false, true>(a, grid, s);
+    return framecode ? launch_eval16r<V, true, false>(a, grid, s) : launch_eval16r<V, false, false>(a, grid, s);
+}
+
+}  // namespace pgd
+
+// needs S >= pgl::FACT_MIN_S, the R weight stream (pack_stream_r), the 16-row bias table (pack_bias_s) and the
+// per-ray records of pg_rayrec.hip in a.rec_ab / a.rec_y
+extern "C" int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream) {
+    using namespace pgd;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return (int)(fp16 ? dispatch_eval16r<f16x8>(*a, framecode, grid, s) : dispatch_eval16r<bf16x8>(*a, framecode, grid, s));
+}

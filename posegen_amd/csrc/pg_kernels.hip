@@ -607,6 +607,75 @@ typedef float cal_f16v __attribute__((ext_vector_type(16)));
 // lane-linear 1-KiB fragment image like the weight ring's), reads issued one MFMA ahead: the structural
 // ceiling of "32 points per wave, weights from LDS" -- what the fused 16-bit kernels could reach if the
 // fragment reads were their only cost.
+// SMALL: the same FLOPs as v_mfma_f32_16x16x32 (two per unit: one A fragment of 16 out channels x 32 k against the
+// two 16-point column tiles of a wave's 32 points).  MI355X_MICROARCH.md (DVFS give-back 7): the chip can hold a
+// higher clock on one MFMA shape than on the other at equal cycles per FLOP, so the shapes are ranked by wall time.
+typedef float cal_f4v __attribute__((ext_vector_type(4)));
+template <bool F16, bool LDSFED>
+__global__ __launch_bounds__(512) void mfma_rate_small_kernel(int iters, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) unsigned frag[32 * 256];
+    const int lane = threadIdx.x & 63;
+    float seed = 0.37f + 0.0131f * (float)lane + 0.00071f * (float)(threadIdx.x >> 6);
+    cal_f4v acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = 0.0f;
+    float av[8], bv[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        seed = seed * 1.6180339f; seed -= floorf(seed);
+        av[e] = seed - 0.5f;
+        seed = seed * 2.2360679f; seed -= floorf(seed);
+        bv[e] = (seed - 0.5f) * 0.25f;
+        seed = seed * 1.7320508f; seed -= floorf(seed);
+        bv[8 + e] = (seed - 0.5f) * 0.25f;
+    }
+    typedef unsigned cal_u4 __attribute__((ext_vector_type(4)));
+    cal_u4 a, b0, b1;
+    if constexpr (F16) {
+        cal_h8 ah, bh, ch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ah[e] = (_Float16)av[e]; bh[e] = (_Float16)bv[e]; ch[e] = (_Float16)bv[8 + e]; }
+        a = __builtin_bit_cast(cal_u4, ah); b0 = __builtin_bit_cast(cal_u4, bh); b1 = __builtin_bit_cast(cal_u4, ch);
+    } else {
+        cal_b8 ab, bb, cb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ab[e] = (__bf16)av[e]; bb[e] = (__bf16)bv[e]; cb[e] = (__bf16)bv[8 + e]; }
+        a = __builtin_bit_cast(cal_u4, ab); b0 = __builtin_bit_cast(cal_u4, bb); b1 = __builtin_bit_cast(cal_u4, cb);
+    }
+    auto mma = [&](cal_f4v& c, const cal_u4& x, const cal_u4& y) {
+        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cal_h8, x), __builtin_bit_cast(cal_h8, y), c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cal_b8, x), __builtin_bit_cast(cal_b8, y), c, 0, 0, 0);
+    };
+    if constexpr (LDSFED) {
+        for (int i = threadIdx.x; i < 32 * 256; i += 512) frag[i] = a[i & 3] ^ (unsigned)(i >> 8) * 0x00010001u;
+        __syncthreads();
+        const cal_u4* img = reinterpret_cast<const cal_u4*>(frag) + lane;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const cal_u4 x = img[u * 64];
+                mma(acc[(2 * u) & 7], x, b0);
+                mma(acc[(2 * u + 1) & 7], x, b1);
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { mma(acc[2 * c], a, b0); mma(acc[2 * c + 1], a, b1); }
+        }
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r += acc[c][e];
+    if (r == 123.456f) sink[0] = r;
+}
+
 template <bool F16, bool LDSFED>
 __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __restrict__ sink) {
     __shared__ __attribute__((aligned(16))) unsigned frag[32 * 256];      // 32 fragments of 1 KiB
@@ -674,6 +743,14 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float* __rest
 // launches `blocks` workgroups x 8 waves x iters x 32 MFMAs; returns 0 or the hipError
 extern "C" int pg_launch_mfma_rate(int f16, int lds_fed, int blocks, int iters, float* sink, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (lds_fed & 2) {      // bit 1: the 16x16x32 shape (same FLOPs per unit)
+        const bool fed = (lds_fed & 1) != 0;
+        if (f16 && fed) hipLaunchKernelGGL((pgk::mfma_rate_small_kernel<true, true>), dim3(blocks), dim3(512), 0, s, iters, sink);
+        else if (f16) hipLaunchKernelGGL((pgk::mfma_rate_small_kernel<true, false>), dim3(blocks), dim3(512), 0, s, iters, sink);
+        else if (fed) hipLaunchKernelGGL((pgk::mfma_rate_small_kernel<false, true>), dim3(blocks), dim3(512), 0, s, iters, sink);
+        else hipLaunchKernelGGL((pgk::mfma_rate_small_kernel<false, false>), dim3(blocks), dim3(512), 0, s, iters, sink);
+        return (int)hipGetLastError();
+    }
     if (f16 && lds_fed) hipLaunchKernelGGL((pgk::mfma_rate_kernel<true, true>), dim3(blocks), dim3(512), 0, s, iters, sink);
     else if (f16) hipLaunchKernelGGL((pgk::mfma_rate_kernel<true, false>), dim3(blocks), dim3(512), 0, s, iters, sink);
     else if (lds_fed) hipLaunchKernelGGL((pgk::mfma_rate_kernel<false, true>), dim3(blocks), dim3(512), 0, s, iters, sink);

@@ -189,6 +189,22 @@ constexpr int BS_RGB = 137;
 constexpr int BS_COUNT = 138;
 constexpr int BIAS16_FLOATS = BS_COUNT * 16;
 
+// ---- per-ray records of the factorised 16-bit path (pg_rayrec.hip writes, pg_eval16r.hip reads) ----------
+// Everything of the embedding that depends on the RAY only is computed once per ray by a small kernel in front of
+// the fused one and handed over through HBM in the exact LDS image the fused kernel wants, so that a workgroup
+// pass fetches it with a handful of LDS-DMA pieces instead of building it (table build + Y stage + two barriers
+// per pass, and 192 KiB of Y-stage weights through the vector memory path per pass, were 13 % of a pass):
+//   AB[ray][joint] = (a = R_j o + t_j, pad, b = R_j d, pad)  8 floats: q = a + z b          (REC_AB_BYTES per ray)
+//   Y [ray][out tile16 t][lane (g, row)] x 16 B = the 8 joint slots of lane group g (vy16_slot_joint) of
+//       Y[ray][j][16 t + row] = sum_k W_vd[16 t + row, (j, k)] T[ray][j][k]                     (REC_Y_BYTES per ray)
+// Both arrays carry REC_PAD_RAYS rays of slack at the end: a pass always fetches MAXR_F rays.
+constexpr int REC_AB_BYTES = J * 32;              // 768
+constexpr int REC_Y_BYTES = (VW / 16) * 64 * 16;  // 8192
+constexpr int REC_PAD_RAYS = 8;
+constexpr int REC_TILE_RAYS = 32;                 // rays per MFMA tile of the record kernel (rows of a 32x32x16 MFMA)
+constexpr int LDS_AB_BYTES = 4096;                // one AB buffer in LDS: MAXR_F x 768 = 3840 -> 4 DMA pieces of 1 KiB
+static_assert(MAXR_F * REC_AB_BYTES <= LDS_AB_BYTES && LDS_AB_BYTES / REC_AB_BYTES + 1 <= REC_PAD_RAYS, "AB fetch stays inside the padded array");
+
 // bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1), folded view (4)
 constexpr int BT_LAYER0 = 0;
 constexpr int BT_FEAT = 64;

@@ -263,6 +263,20 @@ int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out)
     return out.size() == (size_t)S::NCHUNK * CHUNK_BYTES ? 0 : -2;
 }
 
+// ---- pg_eval16r.hip: the same units, with the rgb head's units directly behind the alpha / view segment ----
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
+    std::vector<uint8_t> s;
+    const int rc = pack_stream_s(t, precision, s);
+    if (rc) return rc;
+    // S: [.. | AV: U_AV units, padded to CH_AV chunks | RGB: U_RGB units, padded to 1 chunk]
+    const size_t av0 = (size_t)(S::NCHUNK - 1 - S::CH_AV) * CHUNK_BYTES;
+    out.assign(s.begin(), s.begin() + av0 + (size_t)R::U_AV * UNIT_BYTES);
+    const size_t rgb0 = (size_t)(S::NCHUNK - 1) * CHUNK_BYTES;
+    out.insert(out.end(), s.begin() + rgb0, s.begin() + rgb0 + (size_t)R::U_RGB * UNIT_BYTES);
+    out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
+    return out.size() == (size_t)R::NCHUNK * CHUNK_BYTES ? 0 : -2;
+}
+
 void pack_bias_s(const NetTensors& t, std::vector<float>& out) {
     out.assign(BIAS16_FLOATS, 0.f);
     auto put = [&](int tile, const float* b, int n, int row0) {

@@ -35,6 +35,7 @@ int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, s
 void pack_bias(const NetTensors& t, std::vector<float>& out);
 // stream and bias table of the 16x16x32 kernel (pg_program.h S, pg_layout.h "small tile")
 int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out);
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out);
 void pack_bias_s(const NetTensors& t, std::vector<float>& out);
 // Y-stage weights of the factorised view layer: [wave 8][unit n][64 lanes x 16 B]; unit n of
 // wave w = (joint vy_joint(w, n/2), k-unit n%2) of out tile w&3 as an MFMA B operand.

@@ -75,6 +75,21 @@ constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AV + 1;
 constexpr int MFMA_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + HU16 * (NTV16 + 1) + VW / 32) + 2 * NTV16;
 }  // namespace S
 
+// ---------------- shape R: 16x16x32 tiles, per-ray records (pg_eval16r.hip) ---------------------
+// [L0 k-major][L1..4][L5h][L5x k-major][L6][L7][alpha | folded view: 9 tiles, then the rgb head in the same chunk]
+// The view-direction part of the view layer comes from the per-ray Y records (pg_layout.h), not from the stream.
+namespace R {
+constexpr int UPC = CHUNK_BYTES / UNIT_BYTES;
+constexpr int CH_L0X = cdiv(XU16 * NT16, UPC);          // 7
+constexpr int CH_HID = cdiv(HU16 * NT16, UPC);          // 4
+constexpr int U_AV = HU16 * (NTV16 + 1);                // 72 units: alpha tile + 8 folded view tiles
+constexpr int U_RGB = VW / 32;                          // 4 units, directly behind (no chunk padding in between)
+constexpr int CH_AVR = cdiv(U_AV + U_RGB, UPC);         // 3
+constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 45
+// 16x16x32 MFMAs per 32-point group: two per unit, plus the second stage of the view layer for one ray
+constexpr int MFMA16_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + U_AV + U_RGB) + 2 * NTV16;
+}  // namespace R
+
 // ---------------- shape B: fp32 (UE 4, 1-KiB units) or split 16-bit (UE 8, 2-KiB) ---
 // bytes per sequence position per out tile are the same for both (256 B), so are the chunk counts
 namespace B {

@@ -138,6 +138,12 @@ class HipRenderer:
         self._check(self.lib.pg_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(pts)))
         return n.value, ms.value, pts.value
 
+    def profile_read_aux(self):
+        """(launches, summed device ms) of the per-ray record kernel in front of the factorised 16-bit launches."""
+        n, ms = C.c_int64(), C.c_double()
+        self._check(self.lib.pg_profile_read_aux(self.handle, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def device_info(self):
         n, k = C.c_int32(), C.c_int32()
         self._check(self.lib.pg_device_info(self.handle, C.byref(n), C.byref(k)))
@@ -147,7 +153,7 @@ class HipRenderer:
         """TFLOP/s this device sustains on bare 32x32x16 MFMAs, operands in registers or (lds_fed) the A
         operand read from LDS per MFMA (pg_calibrate_mfma); synchronous."""
         tf, ms = C.c_double(), C.c_double()
-        self._check(self.lib.pg_calibrate_mfma(self.handle, 1 if f16 else 0, 1 if lds_fed else 0, float(min_ms),
+        self._check(self.lib.pg_calibrate_mfma(self.handle, 1 if f16 else 0, int(lds_fed), float(min_ms),
                                                C.byref(tf), C.byref(ms)))
         return {"tflops": tf.value, "ms": ms.value}
 

@@ -19,7 +19,8 @@ import sys
 KERNEL_RE = sys.argv[2] if len(sys.argv) > 2 else r'_ZN3pgd\d+eval\w*_kernel'
 txt = open(sys.argv[1]).read()
 kernels = re.split(r'\n(?=' + KERNEL_RE + ')', txt)
-HAND = re.compile(r'ds_read_b128 v\[(\d+):(\d+)\], v\d+ offset:\d+\*1024')
+# ring reads carry `offset:N*1024`, the reads beside the ring pipe (lds_async128: bias tiles, (a, b) rows) `offset:0+N`
+HAND = re.compile(r'ds_read_b128 v\[(\d+):(\d+)\], v\d+ offset:(?:\d+\*1024|0\+\d+(?:\*64)?)')
 bad = 0
 
 

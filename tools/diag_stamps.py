@@ -24,6 +24,9 @@ names = ["ray table+Y stage", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "alpha tile"
 tot = (st[:, :, 8] - st[:, :, 0]).astype(np.float64)
 print("pass total cycles (s_memtime ticks): mean %.0f  min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
 mf = [24, 216, 512, 344, 256, 16, 72, 8]
+if os.environ.get("POSEGEN_RECORDS", "1") != "0":     # pg_eval16r.hip, in 32x32x16 equivalents
+    names = ["pass prologue", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "alpha tile", "view (trunk+Y)", "rgb+store"]
+    mf = [0, 224, 512, 352, 256, 8, 72, 4]
 for k, nme in enumerate(names):
     m = d[:, :, k].mean()
     print(f"{nme:18s} {m:9.0f} cycles  {100*m/tot.mean():5.1f}%   mfma {mf[k]:4d} -> {m/max(mf[k],1):6.1f} cyc/mfma (ideal 64 for 2 waves/SIMD)")
