@@ -324,6 +324,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     launches, k_ms, k_pts = r.profile_read() if r is not None else (0, 0.0, 0)
+    aux_n, aux_ms = r.profile_read_aux() if r is not None else (0, 0.0)
     if r is not None:
         r.profile_enable(False)
     dt = max_over_ranks(dt)
@@ -364,7 +365,7 @@ def main():
     rays_s = (strong_state["valid"] if strong else world * n) * a.steps / dt
     peak = PEAK_TFLOPS[a.prec]
     k_tflops = k_pts * flops_pt / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    kernel = {"bf16": "eval16_kernel", "fp16": "eval16_kernel", "fp16c": "evalc_kernel"}.get(a.prec, "eval32_kernel")
+    kernel = {"bf16": "eval16r_kernel", "fp16": "eval16r_kernel", "fp16c": "evalc_kernel"}.get(a.prec, "eval32_kernel")
     result = {
         "metric": METRIC,
         "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -390,6 +391,12 @@ def main():
                      # counter traffic (`traffic`, per eval launch) is mostly the raw / z intermediates between them
                      "algorithmic_bytes_per_ray": 64, "algorithmic_bytes_per_frame": 64 * n},
     }
+    if aux_n:
+        # the per-ray record kernel in front of every fused launch (pg_rayrec.hip: what depends on the ray only, once
+        # per ray; HBM-bound): its time is part of ms_per_step, not of the fused kernel's `achieved`
+        result["roofline"]["record_kernel"] = {"kernel": "ray_records_kernel", "launches": aux_n, "avg_launch_ms": aux_ms / aux_n,
+                                               "bytes_written_per_launch": (8192 + 768) * n,
+                                               "frac_incl_records": k_pts * flops_pt / ((k_ms + aux_ms) * 1e-3) / 1e12 / peak}
     if side is not None:
         result["strong_scaling"] = side
     if a.dry_run:

@@ -18,11 +18,9 @@
 #include "pg_pack.h"
 
 extern "C" {
-int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream);
-int pg_launch_eval16s(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_launch_ray_records(const pgd::RecArgs* a, int fp16, int framecode, int n_cu, void* stream);
-int pg_launch_eval16w(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
@@ -72,10 +70,9 @@ struct NetState {
     std::vector<float> codes_host;             // [n_codes+1,16]
     int n_codes = 0;
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
-    uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the factorised view layer
-    uint8_t* d_stream_s[PG_PREC_COUNT] = {};      // 16x16x32 kernel (pg_eval16s.hip): stream, bias table
-    uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip)
-    float* d_bias_s = nullptr;
+    uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the per-ray record kernel (pg_rayrec.hip)
+    uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip): stream,
+    float* d_bias_s = nullptr;                    // ... and its 16-row bias table
     size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
     float* d_codes = nullptr;
@@ -169,8 +166,9 @@ pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     return t;
 }
 
-// The 16-bit kernels factorise the view layer over rays when a pass cannot touch more than
-// MAXR_F rays (pg_layout.h); POSEGEN_VIEW_FACT=0 forces the direct form (A/B, debugging).
+// The 16-bit precisions factorise the view layer over rays when a pass cannot touch more than MAXR_F rays
+// (pg_layout.h): per-ray records (pg_rayrec.hip) + the 16x16x32 kernel (pg_eval16r.hip); POSEGEN_VIEW_FACT=0
+// forces the direct 32x32x16 kernel (pg_eval16.hip) everywhere (A/B, debugging).
 bool use_fact(int prec, int S) {
     static const bool allowed = [] { const char* e = std::getenv("POSEGEN_VIEW_FACT"); return !(e && e[0] == '0'); }();
     return allowed && is_shape_a(prec) && S >= FACT_MIN_S;
@@ -182,26 +180,6 @@ bool use_fact(int prec, int S) {
 bool use_comp_kernel(int prec, int S, bool points) {
     static const bool allowed = [] { const char* e = std::getenv("POSEGEN_COMP_KERNEL"); return !(e && e[0] == '0'); }();
     return allowed && prec == PG_PREC_FP16C && !points && S >= COMP_MIN_S;
-}
-
-// MFMA shape of the factorised 16-bit kernel: 32x32x16 (pg_eval16.hip); POSEGEN_MFMA=16 selects
-// the 16x16x32 variant (pg_eval16s.hip), which measured the same wall time
-bool use_small_tiles() {
-    static const bool on = [] { const char* e = std::getenv("POSEGEN_MFMA"); return e && std::strcmp(e, "16") == 0; }();
-    return on;
-}
-
-// one wave per SIMD x 64 points (pg_eval16w.hip) instead of two x 32: POSEGEN_WAVES=4
-bool use_wide_waves() {
-    static const bool on = [] { const char* e = std::getenv("POSEGEN_WAVES"); return e && std::strcmp(e, "4") == 0; }();
-    return on;
-}
-
-// The factorised 16-bit path: pg_rayrec.hip (per-ray records) + pg_eval16r.hip (16x16x32).  POSEGEN_RECORDS=0 falls
-// back to the 32x32x16 kernel with the in-kernel table build and Y stage (A/B, debugging).
-bool use_records() {
-    static const bool on = [] { const char* e = std::getenv("POSEGEN_RECORDS"); return !(e && e[0] == '0'); }();
-    return on;
 }
 
 int ensure_rec(pg_handle* h, int64_t n) {
@@ -246,25 +224,6 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     return PG_OK;
 }
 
-int ensure_stream_s(pg_handle* h, int which, int prec) {
-    NetState& ns = h->net[which];
-    if (ns.d_stream_s[prec]) return PG_OK;
-    std::vector<uint8_t> packed;
-    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
-    const int rc = pgpack::pack_stream_s(t, prec, packed);
-    if (rc != 0) return fail(h, PG_EINVAL, "16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
-    PG_HIP(h, hipSetDevice(h->device));
-    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_s[prec]), packed.size()));
-    PG_HIP(h, hipMemcpy(ns.d_stream_s[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
-    if (!ns.d_bias_s) {
-        std::vector<float> b;
-        pgpack::pack_bias_s(t, b);
-        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias_s), b.size() * sizeof(float)));
-        PG_HIP(h, hipMemcpy(ns.d_bias_s, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
-    return PG_OK;
-}
-
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -276,19 +235,12 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec][fact]), packed.size()));
     PG_HIP(h, hipMemcpy(ns.d_stream[prec][fact], packed.data(), packed.size(), hipMemcpyHostToDevice));
     ns.stream_bytes[prec][fact] = packed.size();
-    if (fact && is_shape_a(prec) && !ns.d_vy[prec]) {
-        std::vector<uint8_t> vy;
-        if (pgpack::pack_vy(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, vy) != 0)
-            return fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
-        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_vy[prec]), vy.size()));
-        PG_HIP(h, hipMemcpy(ns.d_vy[prec], vy.data(), vy.size(), hipMemcpyHostToDevice));
-    }
     return PG_OK;
 }
 
 // the packed weight streams a precision mode will use for net `which`, built ahead of the first render
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
-    if (is_shape_a(mode) && use_records() && use_fact(mode, FACT_MIN_S)) {
+    if (is_shape_a(mode) && use_fact(mode, FACT_MIN_S)) {
         const int rc = ensure_stream_r(h, which, mode);
         return rc ? rc : ensure_stream(h, which, mode, false);        // + the direct kernel's stream (short rays, points)
     }
@@ -327,21 +279,19 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool compk = !pnoise && use_comp_kernel(prec, S, points != nullptr);
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
-    const bool recs = sa && fact && use_records();                // per-ray records + the 16x16x32 kernel
+    const bool recs = sa && fact;                                 // per-ray records + the 16x16x32 kernel
     int rc = recs ? ensure_stream_r(h, which, prec) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     if (recs && (rc = ensure_rec(h, n))) return rc;
-    const bool small = sa && fact && !recs && use_small_tiles();  // the opt-in variants exist for bf16 / fp16 only
-    if (small && (rc = ensure_stream_s(h, which, prec))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = recs ? ns.d_stream_r[prec] : small ? ns.d_stream_s[prec] : ns.d_stream[prec][fact];
-    a.wy = (fact && !compk) ? ns.d_vy[prec] : nullptr;
-    a.bias = (small || recs) ? ns.d_bias_s : ns.d_bias;
+    a.wstream = recs ? ns.d_stream_r[prec] : ns.d_stream[prec][fact];
+    a.wy = recs ? ns.d_vy[prec] : nullptr;
+    a.bias = recs ? ns.d_bias_s : ns.d_bias;
     if (recs) {
         a.rec_y = h->rec;
         a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES);
@@ -389,9 +339,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
     int e = recs ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : small ? pg_launch_eval16s(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : (sa && fact && use_wide_waves()) ? pg_launch_eval16w(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, fact, grid, stream)
+          : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : compk ? pg_launch_evalc(&a, fc, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
@@ -505,7 +453,6 @@ void pg_destroy(pg_handle* h) {
         for (auto& p : ns.d_stream_r) if (p) (void)hipFree(p);
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
-        for (auto& p : ns.d_stream_s) if (p) (void)hipFree(p);
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
@@ -547,7 +494,6 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
             if (ns.d_stream[p][f]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream[p][f])); ns.d_stream[p][f] = nullptr; }
     for (int p = 0; p < PG_PREC_COUNT; ++p) {
         if (ns.d_vy[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vy[p])); ns.d_vy[p] = nullptr; }
-        if (ns.d_stream_s[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_s[p])); ns.d_stream_s[p] = nullptr; }
         if (ns.d_stream_r[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_r[p])); ns.d_stream_r[p] = nullptr; }
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
@@ -670,7 +616,9 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     pg_config cfg{};
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> packed;
-    const int rc = pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed);
+    const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
+    const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed)
+                         : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed);
     if (rc != 0) return fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
@@ -680,7 +628,8 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     }
     if (bias_out) {
         std::vector<float> bias;
-        pgpack::pack_bias(tensors_of(ns, cfg), bias);
+        if (rprog) pgpack::pack_bias_s(tensors_of(ns, cfg), bias);
+        else pgpack::pack_bias(tensors_of(ns, cfg), bias);
         std::memcpy(bias_out, bias.data(), bias.size() * sizeof(float));
     }
     return PG_OK;
@@ -761,18 +710,18 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     // 16-bit kernels: the factorised-view program (rays with >= 64 samples, the usual case)
     const bool fact = use_fact(precision, FACT_MIN_S);
     const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
-    if (sa && fact && use_records()) {      // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
+    if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
         if (stream_bytes) *stream_bytes = (int64_t)pgp::R::NCHUNK * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
         return PG_OK;
     }
     if (stream_bytes)
-        *stream_bytes = (int64_t)(compk ? pgp::C::NCHUNK : sa ? (fact ? pgp::AF::NCHUNK : pgp::A::NCHUNK)
+        *stream_bytes = (int64_t)(compk ? pgp::C::NCHUNK : sa ? pgp::A::NCHUNK
                                      : (precision == PG_PREC_FP32 ? pgp::B::NCHUNK : pgp::B::NCHUNK_FOLD)) * CHUNK_BYTES;
     if (mfma_per_group) {
         // the fp32 / split kernels keep feature_linear and the direct view layer (13 + 4 out tiles)
         const int64_t direct = pgp::A::MFMA_PER_GROUP(fc) + (NT + 1 + NTV - (NTV + 1)) * pgp::A::HU;
-        *mfma_per_group = compk ? pgp::C::MFMA_PER_GROUP(fc) : sa ? (fact ? pgp::AF::MFMA_PER_GROUP(fc) : pgp::A::MFMA_PER_GROUP(fc))
+        *mfma_per_group = compk ? pgp::C::MFMA_PER_GROUP(fc) : sa ? pgp::A::MFMA_PER_GROUP(fc)
                              : (precision == PG_PREC_FP32 ? direct * 8 : (direct - NT * pgp::A::HU) * (precision == PG_PREC_FP16C ? 2 : 3));
     }
     return PG_OK;

@@ -11,13 +11,10 @@
 // L2 -> LDS in 32-KiB chunks by global_load_lds_dwordx4 into a 3-slot ring (two chunks
 // in flight while one feeds v_mfma_f32_32x32x16).  The 432-wide density input is
 // produced on the fly as B fragments (never stored) and recomputed for the skip layer.
-// The 648-wide view input is either a per-ray sin/cos table in LDS times the per-point
-// cutoff weight (FACT = false, rays with < 64 samples) or factorised over rays
-// (FACT = true: per-ray Y stage + a K=16 contraction over the joints, pg_layout.h);
-// feature_linear is folded into the view layer by the host packer.
-#ifndef PG_PREFETCH
-#define PG_PREFETCH 1         // global inputs of a pass fetched one pass ahead (see the kernel)
-#endif
+// The 648-wide view input is a per-ray sin/cos table in LDS times the per-point cutoff weight (the
+// "direct" view layer); feature_linear is folded into the view layer by the host packer.
+// This is the 16-bit kernel for rays with < 64 samples, explicit points (density queries) and position
+// noise; rays with >= 64 samples run pg_eval16r.hip (16x16x32 MFMAs, per-ray records).
 #include "pg_eval16_common.h"
 
 namespace pgd {
@@ -27,26 +24,21 @@ using namespace pgp::A;
 // TAPS = the debug taps of pg_stage_eval compiled in: a separate instantiation, launched only when a dump
 // is asked for (the cold dump blocks otherwise cost the production kernel spilled registers, and every
 // scratch reload drains the weight DMA with its vmcnt(0))
-template <typename V, bool FC, bool FACT, bool TAPS>
+template <typename V, bool FC, bool TAPS>
 __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
     float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
-    uint8_t* rtf = smem + LDS_RTAB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, pt = lane & 31;
-    StreamOf<FACT, FC> st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
+    StreamA st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING), (uint32_t)lane * 16u};
 
     for (int i = tid; i < BIAS_FLOATS; i += NTHR) bias[i] = a.bias[i];
     // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
-    if (FACT) {     // the pad slots of the Y fragments are read (times a zero weight) but never written
-        for (int i = tid; i < MAXR_F * (4 * 2 * 1024 / 16); i += NTHR)
-            *reinterpret_cast<uint4*>(rtf + (i / 512) * SLOTF_BYTES + SLOTF_Y + (i % 512) * 16) = make_uint4(0, 0, 0, 0);
-    }
     st.start();
 #if defined(PG_YOUNG_PRIO)
     // the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what the
@@ -57,91 +49,35 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
 #if defined(PG_STAMPS)
     unsigned long long stamps[12];
 #endif
-    // Inputs of a pass that come from global memory (its z, the Y-stage weights of the wave, the ray / pose
-    // rows of the table builders), fetched one pass ahead.  Issued and consumed inside the prologue, each of
-    // the six dependent loads exposes its L2 latency behind a vmcnt(0); fetched ahead, one wait at the top of
-    // the pass finds them all there.  (That wait still drains the refill pieces issued since: they are inline
-    // asm, invisible to hipcc's vmcnt count.  Making them visible -- PG_VISIBLE_DMA, the builtin -- turns the
-    // wait into a counted one but makes hipcc wait vmcnt(0) before every LDS read of its own, table and bias
-    // loads included, because it then sees LDS writes in flight: far worse.)
-    [[maybe_unused]] float nx_z = 0.0f;
-    [[maybe_unused]] YWeights<V, FC> nx_yw;
-    [[maybe_unused]] TabIn nx_tin{};
-#define PG_PREFETCH_PASS(itn)                                                              \
-    do {                                                                                   \
-        const long long p0n_ = (long long)(itn) * PTS;                                     \
-        const long long plastn_ = min(p0n_ + PTS - 1, a.n_points - 1);                     \
-        const int r0n_ = (int)(p0n_ / a.S);                                                \
-        nx_z = a.z[min(p0n_ + wave * 32 + pt, a.n_points - 1)];                            \
-        nx_yw.load(a, wave, lane);                                                         \
-        ray_tablef_load<FC>(a, r0n_, (int)(plastn_ / a.S) - r0n_ + 1, nx_tin);             \
-    } while (0)
-    if (FACT && PG_PREFETCH && (int)blockIdx.x < a.n_iters) PG_PREFETCH_PASS(blockIdx.x);
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
-#if defined(PG_ABL_HIDDEN_ONLY)     // timing ablation only (wrong results): a pass = 11 hidden layers (1408 MFMAs),
-        {                           // no table, no embedding, no heads -- the ring/DMA/barrier machinery by itself
-            V fa_[HU], fb_[HU];
-            float t_[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t_[k] = 0.01f * (float)(lane + k) - 0.3f;
-#pragma unroll
-            for (int u = 0; u < HU; ++u) fa_[u] = Op<V>::cvt(t_);
-#pragma clang loop unroll(full)
-            for (int l = 0; l < 11; ++l) {
-                if (l & 1) hidden_layer<V>(fb_, fa_, st, 0, bias, BT_LAYER0 + NT, h_abl(lane));
-                else hidden_layer<V>(fa_, fb_, st, 0, bias, BT_LAYER0 + NT, h_abl(lane));
-            }
-            const long long gp_ = (long long)it * PTS + wave * 32 + (lane & 31);
-            if (gp_ < a.n_points && lane < 32) a.raw[gp_ * 4] = (float)fb_[0][0] + (float)fb_[HU - 1][3];
-            continue;
-        }
-#endif
         PG_STAMP(0);
         const long long p0 = (long long)it * PTS;
         const long long plast = min(p0 + PTS - 1, a.n_points - 1);
         const int r0 = (int)(p0 / a.S);
         const int nr = (int)(plast / a.S) - r0 + 1;
-        [[maybe_unused]] YWeights<V, FC> yw;
-        [[maybe_unused]] float z_pre = 0.0f;
-        if (FACT && PG_PREFETCH) {
-            yw = nx_yw; z_pre = nx_z;
-            const TabIn tin = nx_tin;
-            lds_barrier();                          // previous pass is done with the table
-            ray_tablef_build<V, FC>(a, tin, rtf, nr);
-            lds_barrier();
-            y_stage<V, FC>(yw, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
-        } else {
-        if (FACT) yw.load(a, wave, lane);       // in flight across the barrier and the table build
         lds_barrier();                          // previous pass is done with the table
-        if (FACT) {
-            ray_tablef<V, FC, NTHR>(a, rtf, r0, nr);
-            lds_barrier();
-            y_stage<V, FC>(yw, rtf, nr, wave, lane);    // visible to all after the next chunk barrier
-        } else {
-            ray_table_phase1<NTHR>(a, rtab, r0, nr);
-            lds_barrier();
-            ray_table_phase2<NTHR, true>(rtab, nr);
-            lds_barrier();
-        }
-        }
+        ray_table_phase1<NTHR>(a, rtab, r0, nr);
+        lds_barrier();
+        ray_table_phase2<NTHR, true>(rtab, nr);
+        lds_barrier();
 
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
         const int myr = (int)(gpc / a.S) - r0;
-        const float* slot = FACT ? reinterpret_cast<const float*>(rtf + myr * SLOTF_BYTES) : rtab + myr * SLOT_FLOATS;
-        const float* od = slot + SLOT_O;      // classic table only
+        const float* slot = rtab + myr * SLOT_FLOATS;
+        const float* od = slot + SLOT_O;
         // Lane-dependent bases made opaque: left visible, hipcc materialises one address
         // register per joint (base + h-dependent offset) and spills them; a scratch reload
         // then waits vmcnt(0), i.e. drains the weight DMA that must stay in flight.
-        const float* skb = opaque_ptr(FACT ? slot + SLOTF_AB / 4 + JH * h * 8 : slot + SLOT_SKT + JH * h * 12);
+        const float* skb = opaque_ptr(slot + SLOT_SKT + JH * h * 12);
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
-        const float* tab = FACT ? nullptr : opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
-        const float zz = (FACT && PG_PREFETCH) ? z_pre : (!FACT && a.pts) ? 0.0f : a.z[gpc];
+        const float* tab = opaque_ptr(slot + SLOT_DTAB + h * DSEQ);
+        const float zz = a.pts ? 0.0f : a.z[gpc];
         // p = o + d z as the reference forms it (mul, then add; raycasters.py:658)
         float px = 0.0f, py = 0.0f, pz = 0.0f;
-        if (!FACT) {
+        {
             if (a.pts) {        // density query on explicit points (pg_query_density)
                 px = a.pts[gpc * 3]; py = a.pts[gpc * 3 + 1]; pz = a.pts[gpc * 3 + 2];
             } else {
@@ -154,7 +90,6 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             }
         }
         const QFromRows q_rows{skb, px, py, pz};
-        const QFromAB q_ab{skb, zz};
 
         PG_STAMP(1);
         V fa[HU], fb[HU];
@@ -162,8 +97,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             f32x16 acc[NT];
 #pragma unroll
             for (int o = 0; o < NT; ++o) acc[o] = load_bias(bias, BT_LAYER0 + o, h);
-            if (FACT) x_segment<V>(acc, st, C_L0, q_ab, cutv, tlv);
-            else x_segment<V>(acc, st, C_L0, q_rows, cutv, tlv);
+            x_segment<V>(acc, st, C_L0, q_rows, cutv, tlv);
             if (TAPS && a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
                 for (int o = 0; o < NT; ++o)
@@ -188,8 +122,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
                 acc[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
                 row_tile<V, HU * NT, PG_ASYNC_X>(acc[o], p5, st, o, fa);
             }
-            if (FACT) x_segment<V>(acc, st, C_L5X, q_ab, cutv, tlv);
-            else x_segment<V>(acc, st, C_L5X, q_rows, cutv, tlv);
+            x_segment<V>(acc, st, C_L5X, q_rows, cutv, tlv);
 #pragma unroll
             for (int o = 0; o < NT; ++o) relu_pack<V>(acc[o], fb[2 * o], fb[2 * o + 1], true);
         }
@@ -206,8 +139,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         {
             f32x16 acc[NTV];
             APipe<V> pv;
-            [[maybe_unused]] APipeX<V> pd;
-            [[maybe_unused]] constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
+            APipeX<V> pd;
+            constexpr int TVD = (DU + (FC ? 1 : 0)) * NTV;
             constexpr int TAV = HU * (NTV + 1);
             {
                 f32x16 a0 = load_bias(bias, BT_ALPHA, h);
@@ -225,12 +158,10 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
             for (int jj = 0; jj < JH; ++jj)
             {
                 float qx, qy, qz;
-                if (FACT) q_ab(jj, qx, qy, qz); else q_rows(jj, qx, qy, qz);
+                q_rows(jj, qx, qy, qz);
                 wd[jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
             }
-            if (FACT) {
-                y_apply<V, FC>(acc, rtf, wd, myr, lane);
-            } else {
+            {
     #pragma clang loop unroll(full)
                 for (int uu = 0; uu < DU; ++uu) {
                     const float4 t0 = *reinterpret_cast<const float4*>(tab + uu * 8);
@@ -255,9 +186,6 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
         }
         PG_STAMP(7);
         if (TAPS) dump_frags<V, HU / 2>(a, 9, gp, valid, fg, h);
-        // the next pass's global inputs: in flight through the rgb head and the pass boundary
-        // (unconditional: a conditional re-definition would keep the 100 registers live through the whole pass)
-        if (FACT && PG_PREFETCH) PG_PREFETCH_PASS(min(it + (int)gridDim.x, a.n_iters - 1));
         // ---- rgb head ----
         f32x16 acc = load_bias(bias, BT_RGB, h);
         {
@@ -280,35 +208,29 @@ __global__ __launch_bounds__(NTHR, 2) void eval16_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC, bool FACT, bool TAPS>
+template <typename V, bool FC, bool TAPS>
 static hipError_t launch_eval16(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16_kernel<V, FC, FACT, TAPS>;
-    constexpr int LDS = FACT ? LDS_TOTAL_F : LDS_TOTAL;
+    auto k = eval16_kernel<V, FC, TAPS>;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
-    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS, attr_done);
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL, attr_done);
     if (ae != hipSuccess) return ae;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS, stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDS_TOTAL, stream, a);
     return hipGetLastError();
 }
 
 }  // namespace pgd
 
 template <typename V>
-static hipError_t dispatch_eval16(const pgd::EvalArgs& a, int framecode, int fact, int grid, hipStream_t s) {
+static hipError_t dispatch_eval16(const pgd::EvalArgs& a, int framecode, int grid, hipStream_t s) {
     using namespace pgd;
-    if (a.dbg && a.dbg_stage != 99) {
-        if (fact) return framecode ? launch_eval16<V, true, true, true>(a, grid, s) : launch_eval16<V, false, true, true>(a, grid, s);
-        return framecode ? launch_eval16<V, true, false, true>(a, grid, s) : launch_eval16<V, false, false, true>(a, grid, s);
-    }
-    if (fact) return framecode ? launch_eval16<V, true, true, false>(a, grid, s) : launch_eval16<V, false, true, false>(a, grid, s);
-    return framecode ? launch_eval16<V, true, false, false>(a, grid, s) : launch_eval16<V, false, false, false>(a, grid, s);
+    if (a.dbg && a.dbg_stage != 99) return framecode ? launch_eval16<V, true, true>(a, grid, s) : launch_eval16<V, false, true>(a, grid, s);
+    return framecode ? launch_eval16<V, true, false>(a, grid, s) : launch_eval16<V, false, false>(a, grid, s);
 }
 
-// fact = 1: factorised view layer (needs S >= pgl::FACT_MIN_S and the AF weight stream)
-extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int fact, int grid, void* stream) {
+// the direct-view 16-bit kernel: rays with < pgl::FACT_MIN_S samples, explicit points, position noise
+extern "C" int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return (int)(fp16 ? dispatch_eval16<pgd::f16x8>(*a, framecode, fact, grid, s)
-                      : dispatch_eval16<pgd::bf16x8>(*a, framecode, fact, grid, s));
+    return (int)(fp16 ? dispatch_eval16<pgd::f16x8>(*a, framecode, grid, s) : dispatch_eval16<pgd::bf16x8>(*a, framecode, grid, s));
 }
 
 extern "C" int pg_eval16_points_per_pass(void) { return pgd::PTS; }

@@ -1,7 +1,7 @@
 // pg_eval16_common.h -- building blocks shared by the 16-bit fused embed+MLP kernels
-// (pg_eval16.hip: v_mfma_f32_32x32x16; pg_eval16s.hip: v_mfma_f32_16x16x32): MFMA operand
-// types, the hand-pipelined weight-ring reads, the per-ray tables of the factorised view
-// layer and the embedding math.
+// (pg_eval16.hip: v_mfma_f32_32x32x16, direct view layer; pg_eval16r.hip: v_mfma_f32_16x16x32,
+// per-ray records): MFMA operand types, the hand-pipelined weight-ring reads, LDS reads beside
+// that pipe, the ReLU / 16-bit packing and the embedding math.
 #pragma once
 #include "pg_device.h"
 
@@ -56,9 +56,7 @@ template <> struct Op<f16x8> {
 #ifndef PG_DMA_WAVES
 #define PG_DMA_WAVES 8
 #endif
-// FACT selects the factorised view layer (pg_layout.h) and with it the stream program
-template <bool FACT, bool FC>
-using StreamOf = Stream<NWAVE, (FACT ? pgp::AF::NCHUNK : NCHUNK), PG_DMA_WAVES>;
+using StreamA = Stream<NWAVE, NCHUNK, PG_DMA_WAVES>;
 static_assert(PG_DMA_WAVES == NWAVE || PG_SPREAD_DMA, "the bulk enter() waits vmcnt on every wave");
 
 __device__ __forceinline__ const float* opaque_ptr(const float* p) {
@@ -145,24 +143,9 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
     if (PG_SPREAD_DMA) {
         // refill piece i of the freed slot goes out at unit i*PSTRIDE+PG_DMA_PHASE of this
         // chunk; a segment ending inside the chunk flushes the rest with its last unit
-#if defined(PG_DMA_STAGGER)
-        // the two waves of a SIMD run the same program a few cycles apart: with one phase both stall in the issue
-        // of a refill piece at the same time and the matrix pipe idles; waves NWAVE/2.. issue half a stride later
-        constexpr int PH2 = (PG_DMA_PHASE + PSTRIDE / 2) % PSTRIDE;
-        if (st.wave < NWAVE / 2) {
-            if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
-            if (L == T - 1)
-                for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
-        } else {
-            if (q % PSTRIDE == PH2) st.piece(q / PSTRIDE);
-            if (L == T - 1)
-                for (int i = (q < PH2 ? 0 : (q - PH2) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
-        }
-#else
         if (q % PSTRIDE == PG_DMA_PHASE) st.piece(q / PSTRIDE);
         if (L == T - 1)
             for (int i = (q < PG_DMA_PHASE ? 0 : (q - PG_DMA_PHASE) / PSTRIDE + 1); i < PER; ++i) st.piece(i);
-#endif
     }
     if (PG_EARLY_RETIRE) {
         // The retire "writes" its register as far as hipcc knows, and a VALU write directly
@@ -357,200 +340,6 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
     }
 }
 
-
-// ===================== factorised view layer (pg_layout.h) ===============================
-constexpr int LDS_TOTAL_F = LDS_RTAB + MAXR_F * SLOTF_BYTES;
-#if !defined(PG_RING_EXPERIMENT)
-static_assert(LDS_TOTAL_F <= 160 * 1024, "LDS budget of one CU (factorised view layer)");
-#endif
-
-// Per-ray slots of the factorised path, one thread per (ray, joint):
-//   AB[j] = (a = R_j o + t_j, b = R_j d)                      (core/encoders.py:8-37)
-//   T16[j][k]: the 27 view values of joint j (k = c*9 + row; e = normalize(b), rows e, sin e,
-//   cos e, sin 2e, cos 2e, sin 4e, cos 4e, sin 8e, cos 8e; encoders.py:172-193) as 16-bit MFMA
-//   operands, zero padded to 32; joint JC = the ray's frame code.
-// The global inputs of one (ray, joint) table entry, fetched a PASS AHEAD (ray_tablef_load at the end of
-// the previous pass, ray_tablef_build at the top of this one): a load issued and consumed inside the
-// prologue can only be waited for with vmcnt(0), which drains the two weight chunks the ring keeps in flight.
-struct TabIn { float4 ra, rb, rc; float ry[6]; float cam; };
-
-template <bool FC>
-__device__ __forceinline__ void ray_tablef_load(const EvalArgs& a, int r0, int nr, TabIn& in) {
-    constexpr int NJ = J + (FC ? 1 : 0);
-    const int idx = threadIdx.x;                  // nr * NJ <= MAXR_F * 25 entries: one thread each
-    if (idx >= nr * NJ) return;
-    const int rr = idx / NJ, j = idx - rr * NJ;
-    if (j < J) {
-        const float4* sk = reinterpret_cast<const float4*>(a.skts + (long long)(r0 + rr) * a.pose_stride + j * 16);
-        in.ra = sk[0]; in.rb = sk[1]; in.rc = sk[2];
-        const float* ry = a.rays + (long long)(r0 + rr) * 11;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) in.ry[k] = ry[k];
-    } else {
-        in.cam = a.cams ? a.cams[r0 + rr] : -1.0f;
-    }
-}
-
-template <typename V, bool FC>
-__device__ __forceinline__ void ray_tablef_build(const EvalArgs& a, const TabIn& in, uint8_t* rt, int nr) {
-    constexpr int NJ = J + (FC ? 1 : 0);
-    const int idx = threadIdx.x;
-    if (idx >= nr * NJ) return;
-    {
-        const int rr = idx / NJ, j = idx - rr * NJ;
-        uint8_t* slot = rt + rr * SLOTF_BYTES;
-        float t[TK];
-#pragma unroll
-        for (int k = 0; k < TK; ++k) t[k] = 0.0f;
-        if (j < J) {
-            const float4 ra = in.ra, rb = in.rb, rc = in.rc;
-            const float ox = in.ry[0], oy = in.ry[1], oz = in.ry[2], dx = in.ry[3], dy = in.ry[4], dz = in.ry[5];
-            float e[3];
-            e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
-            e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
-            e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
-            float4* ab = reinterpret_cast<float4*>(slot + SLOTF_AB + j * 32);
-            ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
-                                fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
-                                fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
-            ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
-            const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float ev = e[c] * inv;
-                const float rev = ev * 0.15915494309189535f;
-                float sn = __builtin_amdgcn_sinf(rev), co = __builtin_amdgcn_cosf(rev);
-                t[c * ROWS_D] = ev;
-#pragma unroll
-                for (int f = 0; f < LD; ++f) {
-                    t[c * ROWS_D + 1 + 2 * f] = sn;
-                    t[c * ROWS_D + 2 + 2 * f] = co;
-                    const float s2 = 2.0f * sn * co;
-                    co = (co - sn) * (co + sn);
-                    sn = s2;
-                }
-            }
-        } else {
-            // the code row depends on the (prefetched) index: this one load is waited for in place
-            const int ci = in.cam < 0.0f ? a.n_codes : min((int)in.cam, a.n_codes - 1);
-#pragma unroll
-            for (int k = 0; k < FC_CH; ++k) t[k] = a.codes[ci * FC_CH + k];
-        }
-        V* dst = reinterpret_cast<V*>(slot + SLOTF_T16 + j * (TK * 2));
-#pragma unroll
-        for (int q = 0; q < TK / 8; ++q) dst[q] = Op<V>::cvt(t + 8 * q);
-    }
-}
-
-template <typename V, bool FC, int NTHREADS>
-__device__ __forceinline__ void ray_tablef(const EvalArgs& a, uint8_t* rt, int r0, int nr) {
-    static_assert(MAXR_F * (J + 1) <= NTHREADS, "one thread per (ray, joint) table entry");
-    TabIn in{};
-    ray_tablef_load<FC>(a, r0, nr, in);
-    ray_tablef_build<V, FC>(a, in, rt, nr);
-}
-
-// Y stage: Y[ray][j][o] for the rays of this pass.  Wave w: out tile w&3, the 12 (13 with the
-// frame code) joints of half w>>2; per joint two K=16 MFMAs with A = T16 (rows = rays) and
-// B = the wave's own weight units (pack_vy), read straight from L2 into registers at the top of
-// the pass (no other wave needs them, so they do not go through the LDS ring).  C has the out
-// channel on the lane and rays 0..3 (lanes < 32) / 4..7 in registers 0..3; joint e of the wave
-// lands in 16-bit slot e%8 of the 16 bytes lane (h, o) of the second stage's A fragment
-// (tile, e/8) holds.
-template <typename V, bool FC>
-struct YWeights {
-    static constexpr int NU = pgp::AF::VY_UNITS(FC);
-    uint4 b[NU];
-    __device__ __forceinline__ void load(const EvalArgs& a, int wave, int lane) {
-        // The base is re-defined (opaquely) in every pass: as a loop invariant hipcc forms all NU 64-bit
-        // addresses at kernel entry and keeps them for the whole kernel -- 48 VGPRs, 7 of them spilled,
-        // and every scratch reload waits vmcnt(0), i.e. drains the weight DMA.
-        const uint8_t* wy = a.wy;
-        asm volatile("" : "+s"(wy));
-        const uint4* p = reinterpret_cast<const uint4*>(wy) + ((size_t)wave * NU) * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < NU; ++n) b[n] = p[n * 64];
-    }
-};
-
-template <typename V, bool FC>
-__device__ __forceinline__ void y_stage(const YWeights<V, FC>& yw, uint8_t* rt, int nr, int wave, int lane) {
-    constexpr int NE = JH + (FC ? 1 : 0);
-    using E = typename Op<V>::E;
-    const int t = wave & 3, hw = wave >> 2, hl = lane >> 5, col = lane & 31;
-    const uint8_t* trow = rt + min(col, nr - 1) * SLOTF_BYTES + SLOTF_T16 + hl * 16;
-    const uint8_t* trow_h = trow + hw * (JH * TK * 2);
-    uint8_t* ybase = rt + SLOTF_Y + ((t * 2) * 64 + 32 * hw + col) * 16 + 4 * hl * SLOTF_BYTES;
-    // The wave's joints e = 0..NE-1 of one (ray, out channel) are the 16-bit slots e%8 of the 16 bytes a lane of
-    // the second stage's A fragment (tile, e/8) holds: they are collected in registers and written as TWO 16-byte
-    // stores per ray (64 lanes x 16 B contiguous: conflict-free) instead of NE 2-byte stores at a 16-byte lane
-    // stride (8-way bank conflicts, 100 LDS stores per wave and pass).
-    unsigned pk[4][8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pk[r][q] = 0u;
-    float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma clang loop unroll(full)
-    for (int e = 0; e < NE; ++e) {
-        const uint8_t* tj = e < JH ? trow_h + e * (TK * 2) : trow + JC * (TK * 2);
-        const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj));
-        const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(tj + 32));
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = Op<V>::mfma(a0, __builtin_bit_cast(V, yw.b[2 * e]), acc);
-        acc = Op<V>::mfma(a1, __builtin_bit_cast(V, yw.b[2 * e + 1]), acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {      // ray = r + 4 hl
-            if ((e & 1) == 0 && e + 1 < NE) prev[r] = acc[r];
-            else {
-                const E lo = (E)((e & 1) ? prev[r] : acc[r]);
-                const E hi = (E)((e & 1) ? acc[r] : 0.0f);
-                unsigned short ulo, uhi;
-                __builtin_memcpy(&ulo, &lo, 2);
-                __builtin_memcpy(&uhi, &hi, 2);
-                pk[r][(e / 8) * 4 + (e % 8) / 2] = (unsigned)ulo | ((unsigned)uhi << 16);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)            // only MAXR_F = 5 slots exist: rays 0..3 from lanes < 32, ray 4 from the others
-        if (hl == 0 || r == 0) {
-#pragma unroll
-            for (int g = 0; g < (NE + 7) / 8; ++g)
-                *reinterpret_cast<uint4*>(ybase + r * SLOTF_BYTES + g * 1024) = make_uint4(pk[r][4 * g], pk[r][4 * g + 1], pk[r][4 * g + 2], pk[r][4 * g + 3]);
-        }
-}
-
-// second stage: acc[t] += sum_j w_j Y[ray][j][32t..] for the (at most two) rays of the wave
-template <typename V, bool FC>
-__device__ __forceinline__ void y_apply(f32x16* acc, const uint8_t* rt, const float* wd, int myr, int lane) {
-    const int h = lane >> 5;
-    float wx[16];
-#pragma unroll
-    for (int e = 0; e < JH; ++e) wx[e] = wd[e];
-    wx[12] = (FC && h == 0) ? 1.0f : 0.0f;
-    wx[13] = wx[14] = wx[15] = 0.0f;
-    const u32x4 w0 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx));
-    const u32x4 w1 = __builtin_bit_cast(u32x4, Op<V>::cvt(wx + 8));
-    const int ra = __builtin_amdgcn_readfirstlane(myr);
-    const int rb = __builtin_amdgcn_readlane(myr, 63);
-    for (int ray = ra; ray <= rb; ++ray) {
-        const bool mine = myr == ray;
-        u32x4 b0, b1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { b0[q] = mine ? w0[q] : 0u; b1[q] = mine ? w1[q] : 0u; }
-        const uint8_t* yb = rt + ray * SLOTF_BYTES + SLOTF_Y + lane * 16;
-#pragma unroll
-        for (int t = 0; t < NTV; ++t) {
-            const V a0 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2) * 1024));
-            const V a1 = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(yb + (t * 2 + 1) * 1024));
-            acc[t] = Op<V>::mfma(a0, __builtin_bit_cast(V, b0), acc[t]);
-            acc[t] = Op<V>::mfma(a1, __builtin_bit_cast(V, b1), acc[t]);
-        }
-    }
-}
 
 #if defined(PG_STAMPS)
 #define PG_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; } while (0)

@@ -94,7 +94,14 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
                                             const float* cutv, float tau, HOOK hook) {
     APipeX<V> p;
     constexpr int T = XU16 * NT16;
-    float lo0[8], lo1[8];
+    // values 16, 17 of four joints make one more unit: kept as packed 16-bit pairs (4 + 4 registers instead of 16)
+    unsigned lo0[4] = {0u, 0u, 0u, 0u}, lo1[4] = {0u, 0u, 0u, 0u};
+    auto pack2 = [](float a, float b) {
+        using E = typename Op<V>::E;
+        typedef E e2 __attribute__((ext_vector_type(2)));
+        const e2 v = {(E)a, (E)b};
+        return __builtin_bit_cast(unsigned, v);
+    };
     int uu = 0;
 #if PG_R_ASYNC_AB
     const unsigned ab0 = lds_addr_of(abp0), ab1 = lds_addr_of(abp1);
@@ -133,17 +140,15 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
         joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x1);
 #endif
         const int k = jj < 4 ? jj : jj - 4;
-        lo0[2 * k] = x0[16]; lo0[2 * k + 1] = x0[17];
-        lo1[2 * k] = x1[16]; lo1[2 * k + 1] = x1[17];
+        lo0[k] = pack2(x0[16], x0[17]);
+        lo1[k] = pack2(x1[16], x1[17]);
         mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0), Op<V>::cvt(x1));
         if (jj == 0) hook();
         mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0 + 8), Op<V>::cvt(x1 + 8));
         if (jj == 3 || jj == JG - 1) {
-            if (jj == JG - 1) {
-#pragma unroll
-                for (int e = 4; e < 8; ++e) { lo0[e] = 0.0f; lo1[e] = 0.0f; }
-            }
-            mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(lo0), Op<V>::cvt(lo1));
+            if (jj == JG - 1) { lo0[2] = lo0[3] = 0u; lo1[2] = lo1[3] = 0u; }
+            const u32x4 l0 = {lo0[0], lo0[1], lo0[2], lo0[3]}, l1 = {lo1[0], lo1[1], lo1[2], lo1[3]};
+            mma_row16<V, NT16, T>(acc, p, st, uu++, __builtin_bit_cast(V, l0), __builtin_bit_cast(V, l1));
         }
     }
 }
@@ -272,6 +277,11 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
     st.start();
+#if defined(PG_YOUNG_PRIO)
+    // experiment: the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what
+    // the older one waits for at the chunk barriers: one static priority for that half (no per-segment flips)
+    if (wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(PG_YOUNG_PRIO);
+#endif
     const unsigned bbase = lds_addr_of(bias) + 16 * g;          // this lane group's rows of bias tile 0
     // Ray bookkeeping without a division per pass (a 64-bit divide is ~150 VALU instructions, and both waves of a
     // SIMD would run it at the same time): the pass's first point is sample `off0` of ray `r0`; a pass later both

@@ -109,22 +109,14 @@ constexpr int MAXR = PG_MAXR;                 // rays overlapped by one workgrou
 // The 648 view inputs of a point are w_j(point) * T[ray][j][k]: 27 values k = c*9 + row per
 // joint that depend on the RAY only, times the per-point cutoff weight.  So
 //     W_vd xd = sum_j w_j(point) Y[ray][j][:],   Y[ray][j][o] = sum_k W_vd[o,(j,k)] T[ray][j][k]
-// Y is computed once per workgroup pass for the <= MAXR_F rays it touches ("Y stage": wave w
-// does out tile w&3 for the 12 joints of half w>>2, 2 MFMAs per joint with the rays as rows),
-// then every wave contracts over the joints of its points' ray(s) with two K=16 MFMAs per out
-// tile.  The frame code rides along as pseudo joint JC with weight 1.  Exact in real
-// arithmetic; 164 MFMAs and ~500 VALU ops per 32 points become ~40 and ~60.
+// Y is computed once per RAY by pg_rayrec.hip ("per-ray records" below: wave w does out tile w&3 for
+// the 12 joints of half w>>2, 2 MFMAs per joint with 32 rays as rows), and every wave of the fused
+// kernel contracts over the joints of its points' ray(s) with one K=32 MFMA per out tile16.  The frame
+// code rides along as pseudo joint JC with weight 1.  Exact in real arithmetic.
 constexpr int TK = 32;                  // k padded per joint (27 used; frame code 16)
 constexpr int JC = J;                   // pseudo joint carrying the frame code
-constexpr int MAXR_F = 5;               // rays overlapped by one pass when S >= 64
+constexpr int MAXR_F = 5;               // rays overlapped by one 256-point pass when S >= 64
 constexpr int FACT_MIN_S = 64;
-// Per-ray slot (bytes).  AB: per joint a = R_j o + t_j and b = R_j d (8 floats, 2 pads), so that
-// the bone-local position of a sample is q = a + z b: 3 FMAs per joint instead of 9 + 3.
-constexpr int SLOTF_AB = 0;             // 24 x 8 floats
-constexpr int SLOTF_T16 = J * 32;       // 768: 25 joints x TK 16-bit values
-constexpr int SLOTF_Y = SLOTF_T16 + (J + 1) * TK * 2;   // 2368: [tile 4][u 2][64 lanes] x 16 B
-constexpr int SLOTF_BYTES = SLOTF_Y + 4 * 2 * 1024;     // 10560
-static_assert(SLOTF_T16 % 16 == 0 && SLOTF_Y % 16 == 0 && SLOTF_BYTES % 16 == 0, "LDS alignment");
 // view-input column (0 .. 647 + 16) multiplied by value k of joint j; -1 = zero pad
 PG_HD constexpr int vd_channel(int j, int k) {
     if (j < J) return k < 3 * ROWS_D ? (k % ROWS_D) * (3 * J) + 3 * j + k / ROWS_D : -1;
@@ -133,12 +125,6 @@ PG_HD constexpr int vd_channel(int j, int k) {
 // joint the Y-stage wave w (half w>>2) handles as its e-th (0..12); -1 = none
 PG_HD constexpr int vy_joint(int w, int e, bool fc) {
     return e < JH ? JH * (w >> 2) + e : ((fc && (w >> 2) == 0 && e == JH) ? JC : -1);
-}
-// joint in slot e of k-unit u for lane half h in the second stage; -1 = zero
-PG_HD constexpr int vy_slot_joint(int u, int h, int e, bool fc) {
-    if (u == 0) return JH * h + e;
-    if (e < 4) return JH * h + 8 + e;
-    return (fc && h == 0 && e == 4) ? JC : -1;
 }
 
 // ---- per-ray LDS slot of the compensated-fp16 kernel (pg_evalc.hip), floats -----------------
@@ -152,7 +138,7 @@ constexpr int MAXR_C = 5;                         // rays overlapped by a 128-po
 constexpr int COMP_MIN_S = 32;
 static_assert(SLOTC_FLOATS % 4 == 0 && SLOTC_DTAB % 4 == 0 && SLOTC_CODE % 4 == 0, "LDS alignment");
 
-// ---- "small tile" layout of pg_eval16s.hip (v_mfma_f32_16x16x32, factorised view layer) ----
+// ---- "small tile" layout of pg_eval16r.hip (v_mfma_f32_16x16x32, factorised view layer) ----
 // A = weights 16 out channels x 32 k, B = activations 32 k x 16 points, C = 16 x 16: lane
 // (g = lane>>4, col = lane&15) holds rows 4g..4g+3.  A wave still owns 32 points = two column
 // tiles c (points 16c + col), every A fragment feeding both; k-unit u of the next layer is

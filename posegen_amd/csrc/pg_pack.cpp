@@ -124,7 +124,7 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
         s.push_back({MAT_ALPHA, 1, true, {hid(0)}});
         s.push_back({fold_b ? MAT_VIEWF : MAT_VIEW, NTV, km, {hid(0)}});
     }
-    if (!fact) {
+    {
         Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
         if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
         s.push_back(v);
@@ -142,7 +142,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const bool comp = precision == PG_PREC_FP16C;
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3 || comp;     // two planes per unit
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
-    if (fact && shape == SHAPE_B) return -3;
+    if (fact && shape != SHAPE_C) return -3;       // only PG_PREC_FP16C has a second program here (16-bit rays with >= 64 samples: pack_stream_r)
     if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
@@ -194,7 +194,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         }
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    const size_t nchunk = shape == SHAPE_A ? (fact ? AF::NCHUNK : A::NCHUNK)
+    const size_t nchunk = shape == SHAPE_A ? (size_t)A::NCHUNK
                         : shape == SHAPE_C ? (size_t)C::NCHUNK : (split ? B::NCHUNK_FOLD : B::NCHUNK);
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
@@ -203,12 +203,12 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
 int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& out) {
     if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
     const bool is_bf = precision == PG_PREC_BF16;
-    out.assign((size_t)AF::VY_BYTES(fc), 0);
+    out.assign((size_t)R::VY_BYTES(fc), 0);
     for (int w = 0; w < 8; ++w)
-        for (int n = 0; n < AF::VY_UNITS(fc); ++n) {
+        for (int n = 0; n < R::VY_UNITS(fc); ++n) {
             const int j = vy_joint(w, n / 2, fc), ku = n % 2;
             if (j < 0) continue;
-            const size_t base = ((size_t)w * AF::VY_UNITS(fc) + n) * UNIT_BYTES;
+            const size_t base = ((size_t)w * R::VY_UNITS(fc) + n) * UNIT_BYTES;
             // lane (hl, col) = out channel 32(w&3)+col, values k = 16ku + 8hl + 0..7 of joint j
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
@@ -222,20 +222,21 @@ int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& o
     return 0;
 }
 
-// ---- 16x16x32 kernel: units are 16 out rows x 32 k; lane (g, row) holds k = 32u + 8g + 0..7 ----
-int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
+// ---- 16x16x32 kernel (pg_eval16r.hip): units are 16 out rows x 32 k; lane (g, row) holds k = 32u + 8g + 0..7.
+// Segments start on chunk boundaries, except the rgb head, which follows the alpha / view tiles directly. ----
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
     if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
     if (t.viewf_w.size() != (size_t)VW * W) return -4;
     const bool is_bf = precision == PG_PREC_BF16;
-    struct Seg { int mat, no, nu; bool kmajor, xseq; int colbase; };
+    struct Seg { int mat, no, nu; bool kmajor, xseq; int colbase; bool pad; };
     std::vector<Seg> prog;
-    prog.push_back({MAT_L0, NT16, XU16, true, true, 0});
-    for (int l = 1; l <= 4; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0});
-    prog.push_back({MAT_L0 + 5, NT16, HU16, false, false, CH_X});
-    prog.push_back({MAT_L0 + 5, NT16, XU16, true, true, 0});
-    for (int l = 6; l <= 7; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0});
-    prog.push_back({MAT_ALPHA_VIEWF, NTV16 + 1, HU16, false, false, 0});
-    prog.push_back({MAT_RGB, 1, VW / 32, false, false, 0});
+    prog.push_back({MAT_L0, NT16, XU16, true, true, 0, true});
+    for (int l = 1; l <= 4; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0, true});
+    prog.push_back({MAT_L0 + 5, NT16, HU16, false, false, CH_X, true});
+    prog.push_back({MAT_L0 + 5, NT16, XU16, true, true, 0, true});
+    for (int l = 6; l <= 7; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0, true});
+    prog.push_back({MAT_ALPHA_VIEWF, NTV16 + 1, HU16, false, false, 0, false});
+    prog.push_back({MAT_RGB, 1, VW / 32, false, false, 0, true});
     out.clear();
     for (const Seg& sg : prog) {
         for (int L = 0; L < sg.nu * sg.no; ++L) {
@@ -258,22 +259,8 @@ int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out)
                 }
             }
         }
-        out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
+        if (sg.pad) out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    return out.size() == (size_t)S::NCHUNK * CHUNK_BYTES ? 0 : -2;
-}
-
-// ---- pg_eval16r.hip: the same units, with the rgb head's units directly behind the alpha / view segment ----
-int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
-    std::vector<uint8_t> s;
-    const int rc = pack_stream_s(t, precision, s);
-    if (rc) return rc;
-    // S: [.. | AV: U_AV units, padded to CH_AV chunks | RGB: U_RGB units, padded to 1 chunk]
-    const size_t av0 = (size_t)(S::NCHUNK - 1 - S::CH_AV) * CHUNK_BYTES;
-    out.assign(s.begin(), s.begin() + av0 + (size_t)R::U_AV * UNIT_BYTES);
-    const size_t rgb0 = (size_t)(S::NCHUNK - 1) * CHUNK_BYTES;
-    out.insert(out.end(), s.begin() + rgb0, s.begin() + rgb0 + (size_t)R::U_RGB * UNIT_BYTES);
-    out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     return out.size() == (size_t)R::NCHUNK * CHUNK_BYTES ? 0 : -2;
 }
 

@@ -28,16 +28,15 @@ struct NetTensors {
 };
 
 // Packs the weight stream for `precision`; returns 0, or <0 on an internal layout error.
-// `fact` selects the factorised-view program of the 16-bit kernels (pg_program.h AF), or, for
-// PG_PREC_FP16C, the program of the dedicated kernel pg_evalc.hip (pg_program.h C).
+// `fact`: for PG_PREC_FP16C, the program of the dedicated kernel pg_evalc.hip (pg_program.h C); the 16-bit
+// precisions' second program (rays with >= 64 samples, pg_eval16r.hip) is pack_stream_r.
 int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
                 std::vector<int>* seg_chunk_base = nullptr);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
-// stream and bias table of the 16x16x32 kernel (pg_program.h S, pg_layout.h "small tile")
-int pack_stream_s(const NetTensors& t, int precision, std::vector<uint8_t>& out);
+// stream and bias table of the 16x16x32 kernel (pg_program.h R, pg_layout.h "small tile")
 int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out);
 void pack_bias_s(const NetTensors& t, std::vector<float>& out);
-// Y-stage weights of the factorised view layer: [wave 8][unit n][64 lanes x 16 B]; unit n of
+// Y-stage weights of the record kernel (pg_rayrec.hip): [wave 8][unit n][64 lanes x 16 B]; unit n of
 // wave w = (joint vy_joint(w, n/2), k-unit n%2) of out tile w&3 as an MFMA B operand.
 int pack_vy(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out);
 

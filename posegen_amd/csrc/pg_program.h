@@ -5,7 +5,8 @@
 // ([o][u]) or k-major ([u][o]); its units are laid out linearly in consumption order
 // and the segment is padded to a whole number of 16-KiB chunks.
 //
-//   shape A  (pg_eval16.hip: bf16 / fp16, one MFMA per unit, 8 waves x 32 points)
+//   shape A  (pg_eval16.hip: bf16 / fp16, one MFMA per unit, 8 waves x 32 points, direct view layer)
+//   shape R  (pg_eval16r.hip: bf16 / fp16, 16x16x32 tiles, per-ray records: rays with >= 64 samples)
 //   shape B  (pg_eval32.hip: fp32 / bf16x3 / fp16x3, k-major everywhere, 4 waves)
 #pragma once
 #include "pg_layout.h"
@@ -50,31 +51,6 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 }
 }  // namespace A
 
-// ---------------- shape A with the factorised view layer (pg_layout.h) ---------------
-// stream: [L0][L1..4][L5h][L5x][L6][L7][alpha+view][rgb]; the Y-stage weights are a separate
-// per-wave array read straight from L2 into registers (VY_UNITS units of 1 KiB per wave)
-namespace AF {
-constexpr int VY_UNITS(bool fc) { return 2 * (JH + (fc ? 1 : 0)); }                // 24 / 26
-constexpr int VY_BYTES(bool fc) { return 8 * VY_UNITS(fc) * UNIT_BYTES; }
-constexpr int NCHUNK = 2 * A::CH_L0X + 7 * A::CH_HID + A::CH_AV + 1;
-// MFMAs per 32-point group: the trunk as in A, 2*(12|13) Y-stage + 8 or 16 second-stage ones
-constexpr int MFMA_PER_GROUP(bool fc) {
-    return A::MFMA_PER_GROUP(false) - A::DU * NTV + VY_UNITS(fc) + 8;
-}
-}  // namespace AF
-
-// ---------------- shape S: 16x16x32 tiles, factorised view layer (pg_eval16s.hip) -----
-// [L0 k-major][L1..4][L5h][L5x k-major][L6][L7][alpha | folded view: 9 tiles][rgb]
-namespace S {
-constexpr int UPC = CHUNK_BYTES / UNIT_BYTES;
-constexpr int CH_L0X = cdiv(XU16 * NT16, UPC);          // 7
-constexpr int CH_HID = cdiv(HU16 * NT16, UPC);          // 4
-constexpr int CH_AV = cdiv(HU16 * (NTV16 + 1), UPC);    // 3
-constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AV + 1;
-// 16x16x32 MFMAs per 32-point group (two per unit), without the Y stage (those are 32x32x16)
-constexpr int MFMA_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + HU16 * (NTV16 + 1) + VW / 32) + 2 * NTV16;
-}  // namespace S
-
 // ---------------- shape R: 16x16x32 tiles, per-ray records (pg_eval16r.hip) ---------------------
 // [L0 k-major][L1..4][L5h][L5x k-major][L6][L7][alpha | folded view: 9 tiles, then the rgb head in the same chunk]
 // The view-direction part of the view layer comes from the per-ray Y records (pg_layout.h), not from the stream.
@@ -88,6 +64,10 @@ constexpr int CH_AVR = cdiv(U_AV + U_RGB, UPC);         // 3
 constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 45
 // 16x16x32 MFMAs per 32-point group: two per unit, plus the second stage of the view layer for one ray
 constexpr int MFMA16_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + U_AV + U_RGB) + 2 * NTV16;
+// Y-stage weights of the record kernel (pg_rayrec.hip): per wave (out tile w&3, joint half w>>2) two B fragments
+// of 1 KiB per joint (k-units 0, 1), the frame-code pseudo joint behind the 12 joints of the half
+constexpr int VY_UNITS(bool fc) { return 2 * (JH + (fc ? 1 : 0)); }                // 24 / 26
+constexpr int VY_BYTES(bool fc) { return 8 * VY_UNITS(fc) * UNIT_BYTES; }
 }  // namespace R
 
 // ---------------- shape B: fp32 (UE 4, 1-KiB units) or split 16-bit (UE 8, 2-KiB) ---

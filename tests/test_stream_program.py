@@ -242,6 +242,107 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
     return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
 
 
+# ---- the 16x16x32 program of pg_eval16r.hip (pg_program.h R, pg_layout.h "small tile") ----
+JG, NT16, NTV16, HU16, XU16 = 6, 16, 8, 8, 14
+BS_ALPHA, BS_VIEWF, BS_RGB = 128, 129, 137
+
+
+def hseq16_channel(i, g):
+    return 16 * (2 * (i // 8) + ((i % 8) >> 2)) + 4 * g + (i & 3)
+
+
+def xseq16_channel(i, g):
+    u, e = divmod(i, 8)
+    if u < 8:
+        jj, q = u // 2, 8 * (u % 2) + e
+    elif u == 8:
+        jj, q = e // 2, 16 + e % 2
+    elif u < 13:
+        jj, q = 4 + (u - 9) // 2, 8 * ((u - 9) % 2) + e
+    else:
+        if e >= 4:
+            return -1
+        jj, q = 4 + e // 2, 16 + e % 2
+    j = JG * g + jj
+    return q * J + j if q < 15 else 360 + 3 * j + (q - 15)
+
+
+def vy16_slot_joint(g, e, fc):
+    return JG * g + e if e < JG else (J if fc and g == 0 and e == JG else -1)
+
+
+def emulate_r(stream, bias16, chunk_bytes, prec, x, cfg, fact):
+    """x: [32 pts, 1080(+code16)] -> raw [32, 4] through the R stream exactly as pg_eval16r.hip consumes it:
+    units of 16 out rows x 32 k (lane (g, row): k = 32 u + 8 g + e), layer 0 and the skip layer's x part k-major
+    over 16 out tiles, everything else out-tile-major, the rgb head's 4 units in the chunk the view tiles end in,
+    the view-direction part from the per-ray Y record (fact = (tray [25,32], wpt [32,24], vy))."""
+    upc = chunk_bytes // 1024
+    state = {"chunk": -1}
+
+    def unit(pos_in_segment, cont_base=None):
+        if cont_base is None:
+            if pos_in_segment % upc == 0:
+                state["chunk"] += 1
+            q = pos_in_segment % upc
+        else:
+            q = cont_base + pos_in_segment                  # continuation of the current chunk (rgb head)
+            assert q < upc
+        off = state["chunk"] * chunk_bytes + q * 1024
+        raw = stream[off:off + 1024].reshape(64, 16)
+        v = ((raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32) if prec == PREC_BF16
+             else raw.view(np.float16).astype(np.float32)).reshape(4, 16, 8)
+        return v.transpose(1, 0, 2)                         # [row, g, e]
+
+    def seq_vals(fn, n, src):
+        v = np.zeros((4, n, 32), dtype=np.float32)
+        for g in range(4):
+            for i in range(n):
+                ch = fn(i, g)
+                if ch >= 0:
+                    v[g, i] = src[:, ch]
+        return q16(v, prec)
+
+    def bias_tile(t):
+        return np.repeat(bias16[t * 16:(t + 1) * 16].reshape(16, 1), 32, axis=1)       # row = 4 g + r
+
+    def segment(no, kmajor, vals, nu, acc, cont_base=None):
+        for L in range(nu * no):
+            ui, o = (L // no, L % no) if kmajor else (L % nu, L // nu)
+            acc[o] += np.einsum("rge,gep->rp", unit(L, cont_base), vals[:, ui * 8:(ui + 1) * 8, :])
+        return acc
+
+    def hidden_vals(tiles):
+        act = np.maximum(np.concatenate(tiles, 0), 0)      # [channels, pts]
+        return seq_vals(hseq16_channel, len(tiles) * 4, act.T)
+
+    xs = seq_vals(xseq16_channel, XU16 * 8, x[:, :432])
+    tiles = segment(NT16, True, xs, XU16, [bias_tile(o) for o in range(NT16)])
+    hv = hidden_vals(tiles)
+    for l in range(1, 5):
+        hv = hidden_vals(segment(NT16, False, hv, HU16, [bias_tile(l * NT16 + o) for o in range(NT16)]))
+    tiles = segment(NT16, False, hv, HU16, [bias_tile(5 * NT16 + o) for o in range(NT16)])
+    tiles = segment(NT16, True, xs, XU16, tiles)
+    hv = hidden_vals(tiles)
+    for l in (6, 7):
+        hv = hidden_vals(segment(NT16, False, hv, HU16, [bias_tile(l * NT16 + o) for o in range(NT16)]))
+    av = segment(NTV16 + 1, False, hv, HU16, [bias_tile(BS_ALPHA + o) for o in range(NTV16 + 1)])
+    sigma, vt = av[0][0], av[1:]
+    fc = bool(cfg.framecode_ch)
+    yq = y_stage(fact[2], fact[0], fc, prec)                # the ray's Y record [25, 128], 16-bit
+    wq = q16(fact[1].astype(np.float32), prec)              # [pt, 24]
+    for g in range(4):
+        for e in range(8):
+            j = vy16_slot_joint(g, e, fc)
+            if j < 0:
+                continue
+            wj = wq[:, j] if j < J else np.ones(32, dtype=np.float32)
+            for t in range(NTV16):
+                vt[t] += np.outer(yq[j, 16 * t:16 * t + 16], wj)
+    gv = hidden_vals(vt)
+    rgb = segment(1, False, gv, VW // 32, [bias_tile(BS_RGB)], cont_base=(HU16 * (NTV16 + 1)) % upc)[0]
+    return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), state["chunk"] + 1
+
+
 def emulate_c(stream, bias, chunk_bytes, x, cfg):
     """The compensated-fp16 program (pg_program.h C, pg_evalc.hip): every segment k-major, every
     (input unit, out tile) a PAIR of 1-KiB units -- plane 0 = (S-1) f16(W/S) against x1 = f16(x),
@@ -377,6 +478,9 @@ def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
     else:
         ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
         x_em = x
-    raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg, fact_in)
+    if fact:        # 16-bit precisions, rays with >= 64 samples: the 16x16x32 kernel with per-ray records
+        raw, n_chunks = emulate_r(stream, bias, chunk_bytes, prec, x_em, cfg, fact_in)
+    else:
+        raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg, None)
     assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
     np.testing.assert_allclose(raw, ref, rtol=0, atol=tol * max(1.0, float(np.abs(ref).max()) / 10))

@@ -18,7 +18,7 @@ $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unkn
     -input=/dev/null -input=$out/${base}_$name.hsaco -output=$out/${base}_$name.hipfb
 /opt/rocm/bin/hipcc $FLAGS "$@" --cuda-host-only -c $src -Xclang -fcuda-include-gpubinary -Xclang $out/${base}_$name.hipfb -o $out/${base}_$name.o
 objs=""
-for o in pg_api pg_eval16 pg_eval16s pg_eval16w pg_eval32 pg_evalc pg_kernels pg_pack; do
+for o in pg_api pg_eval16 pg_eval16r pg_rayrec pg_eval32 pg_evalc pg_kernels pg_pack; do
   if [ "$o" = "$base" ]; then objs="$objs $out/${base}_$name.o"; else objs="$objs ../_lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $objs

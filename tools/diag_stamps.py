@@ -14,8 +14,6 @@ for rep in range(2):
     raw, dbg = r.stage_eval(0, rb, z, skts, want_dbg=True, dbg_stage=99)
 torch.cuda.synchronize()
 full = dbg.view(torch.int64).cpu().numpy().reshape(-1)[: 64 * 8 * 16].reshape(64, 8, 16)
-if os.environ.get("POSEGEN_WAVES") == "4":      # one-wave-per-SIMD kernel: rows 4..7 unused
-    full = full[:, :4]
 st = full[:, :, :9]
 print("per pass per wave: cycles waiting in vmcnt (weight DMA) %.0f, in s_barrier %.0f" % (full[1:, :, 9].mean(), full[1:, :, 10].mean()))
 print("   by wave: vmcnt", full[1:, :, 9].mean(0).astype(int).tolist(), " barrier", full[1:, :, 10].mean(0).astype(int).tolist())
@@ -24,7 +22,7 @@ names = ["ray table+Y stage", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "alpha tile"
 tot = (st[:, :, 8] - st[:, :, 0]).astype(np.float64)
 print("pass total cycles (s_memtime ticks): mean %.0f  min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
 mf = [24, 216, 512, 344, 256, 16, 72, 8]
-if os.environ.get("POSEGEN_RECORDS", "1") != "0":     # pg_eval16r.hip, in 32x32x16 equivalents
+if True:     # pg_eval16r.hip, in 32x32x16 equivalents
     names = ["pass prologue", "L0 (x)", "L1-4", "L5 (h+x)", "L6-7", "alpha tile", "view (trunk+Y)", "rgb+store"]
     mf = [0, 224, 512, 352, 256, 8, 72, 4]
 for k, nme in enumerate(names):
