@@ -135,8 +135,8 @@ def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays, what):
 def timed_rays(r, dev, rb, skts, cyl, cfg, steps, cams=None):
     """(rays/s, ms/frame, kernel TFLOP/s on algorithmic flops) of `steps` render_rays calls."""
     import torch
-    r.render_rays(rb[: max(rb.shape[0] // 8, 4096)], skts, cyl, cams=None if cams is None else cams[: max(rb.shape[0] // 8, 4096)],
-                  n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
+    # one untimed call at full size: workspaces and the per-ray record buffer are sized by the first call
+    r.render_rays(rb, skts, cyl, cams=cams, n_samples=cfg.n_samples, n_importance=cfg.n_importance, want_alpha=False)
     torch.cuda.synchronize(dev)
     r.profile_enable(True)
     r.profile_read()

@@ -191,15 +191,14 @@ int ensure_rec(pg_handle* h, int64_t n) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->rec), want);
     if (e != hipSuccess) return fail(h, PG_ENOMEM, "ray record buffer of %zu bytes failed: %s", want, hipGetErrorString(e));
     h->rec_bytes = want;
-    // the padding rays behind the last record are fetched (never used): keep them finite
-    PG_HIP(h, hipMemset(h->rec, 0, want));
     return PG_OK;
 }
 
 int ensure_stream_r(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
-    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    if (ns.d_stream_r[prec] && ns.d_bias_s && ns.d_vy[prec]) return PG_OK;
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);        // (folds feature_linear into the view layer: milliseconds of host work)
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_stream_r[prec]) {
         std::vector<uint8_t> packed;
@@ -240,13 +239,16 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
 
 // the packed weight streams a precision mode will use for net `which`, built ahead of the first render
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
-    if (is_shape_a(mode) && use_fact(mode, FACT_MIN_S)) {
-        const int rc = ensure_stream_r(h, which, mode);
-        return rc ? rc : ensure_stream(h, which, mode, false);        // + the direct kernel's stream (short rays, points)
-    }
-    if (mode != PG_PREC_FP16M) return ensure_stream(h, which, mode, use_fact(mode, FACT_MIN_S));
-    int rc = ensure_stream(h, which, PG_PREC_FP16C, use_fact(PG_PREC_FP16C, FACT_MIN_S));
-    if (!rc && which == 0) rc = ensure_stream(h, which, PG_PREC_FP16, use_fact(PG_PREC_FP16, FACT_MIN_S));
+    auto one = [&](int prec) {
+        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) {       // + the direct kernel's stream (short rays, points)
+            const int rc = ensure_stream_r(h, which, prec);
+            return rc ? rc : ensure_stream(h, which, prec, false);
+        }
+        return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
+    };
+    if (mode != PG_PREC_FP16M) return one(mode);
+    int rc = one(PG_PREC_FP16C);
+    if (!rc && which == 0) rc = one(PG_PREC_FP16);
     return rc;
 }
 
@@ -295,6 +297,11 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     if (recs) {
         a.rec_y = h->rec;
         a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES);
+        // the padding rays behind the last record are fetched by the last passes (their values are multiplied by
+        // zero weights at most): keep them finite whatever the buffer held before
+        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * REC_Y_BYTES, 0, (size_t)REC_PAD_RAYS * REC_Y_BYTES, static_cast<hipStream_t>(stream)));
+        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES + (size_t)n * REC_AB_BYTES, 0,
+                                 (size_t)REC_PAD_RAYS * REC_AB_BYTES, static_cast<hipStream_t>(stream)));
     }
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;

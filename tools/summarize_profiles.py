@@ -31,14 +31,14 @@ def counters(path):
 
 def main():
     src, prefix = sys.argv[1], sys.argv[2]
-    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], prefix + "_kernel_stats.csv")
+        shutil.copy(stats[-1], prefix + "_kernel_stats.csv")        # (gpurun merges directories: the newest run counts)
     rows = []
     merged = defaultdict(dict)
     nl = {}
-    for sub in ("fetch", "write", "mfma", "sq"):
-        for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for sub in ("fetch", "write", "mfma", "sq", "lds"):
+        for path in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
             per, launches = counters(path)
             for k, cs in per.items():
                 for c, v in cs.items():
@@ -60,6 +60,12 @@ def main():
                "formula": "2 x FETCH_SIZE (gfx950 unit correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, "
                           "separate --pmc passes, mean over the eval launches of the pass (coarse + fine)",
                "counters_per_launch": {n: m[n] for n in sorted(m)}}
+        # the whole frame: every kernel of the pass, launches per frame = launches / (eval launches / 2)
+        frames = nl[k] / 2.0
+        per_kernel = {kk: (2 * merged[kk].get("FETCH_SIZE", 0) + merged[kk].get("WRITE_SIZE", 0)) * 1024 * nl[kk] / frames
+                      for kk in merged if "mfma_rate" not in kk}
+        out["hbm_bytes_per_frame"] = sum(per_kernel.values())
+        out["hbm_bytes_per_frame_by_kernel"] = {kk.split("(")[0][-60:]: v for kk, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; BUSY_CYCLES over all SIMDs
             cyc = m["GRBM_GUI_ACTIVE"] / 8
