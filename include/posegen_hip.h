@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 5
+#define PG_ABI_VERSION 6
 
 /* error codes */
 #define PG_OK 0
@@ -202,6 +202,37 @@ int pg_render_rays_train(pg_handle* h, void* stream, int64_t n, const float* ray
                          const float* cyls, int64_t cyl_stride, const float* cams,
                          int n_samples, int n_importance, int flags,
                          const pg_train_draws* draws, const pg_outputs* out);
+
+/* ---- the training step (backward through embedding inputs, MLP and compositing) ----
+ * Replaces `render(..., **render_kwargs_train)` + `loss.backward()` of Trainer.train_batch (core/trainer.py:232-275,
+ * 463) for one ray batch, in exact fp32 arithmetic.  The parameters are the CALLER's device tensors (a torch
+ * optimiser owns them), nn.Linear layout, the 24 tensors of pg_load_weights' order; `codes` = framecodes.codes.weight
+ * with the MEAN ROW APPENDED ([n_codes + 1, 16], embedding.py:25-26), NULL without frame codes. */
+typedef struct pg_net_params {
+    const float* w[24];
+    const float* codes;
+    int32_t n_codes;
+} pg_net_params;
+/* gradients, device, same shapes as the parameters (codes: [n_codes, 16], the mean row's share spread over all rows);
+ * OVERWRITTEN by pg_train_backward */
+typedef struct pg_net_grads {
+    float* w[24];
+    float* codes;
+} pg_net_grads;
+
+/* Forward of RayCaster.render_rays in training mode (core/raycasters.py:361-474; draws as in pg_render_rays_train,
+ * may be NULL) with every activation kept on a tape inside the handle: arguments as pg_render_rays; `fine` may be
+ * NULL when n_importance == 0.  The parameter tensors and the tape stay in use until pg_train_backward. */
+int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts, int64_t pose_stride,
+                     const float* cyls, int64_t cyl_stride, const float* cams, int n_samples, int n_importance, int flags,
+                     const pg_train_draws* draws, const pg_net_params* coarse, const pg_net_params* fine, const pg_outputs* out);
+
+/* Backward of the last pg_train_forward: given dL/d(rgb_map) [n,3], dL/d(acc_map) [n], dL/d(rgb0) [n,3], dL/d(acc0) [n]
+ * (device, any may be NULL = zero; what Trainer.compute_loss reads, core/trainer.py:321-383), the gradient of L with
+ * respect to every parameter tensor of both nets.  The importance samples are constants (`z_samples.detach()`,
+ * core/utils/ray_utils.py:285). */
+int pg_train_backward(pg_handle* h, void* stream, const float* d_rgb_map, const float* d_acc_map, const float* d_rgb0,
+                      const float* d_acc0, const pg_net_grads* coarse, const pg_net_grads* fine);
 
 /* One frame with its front and back end on the device.  Replaces, per
  * frame: get_rays + the bounding-box gather of kp_to_valid_rays (core/utils/ray_utils.py:6-28,

@@ -469,7 +469,7 @@ def importance_z(z, weights, n_importance: int, u_rand=None):
     b_lo, b_hi = torch.gather(mids, 1, lo), torch.gather(mids, 1, hi)
     den = c_hi - c_lo
     den = torch.where(den < 1e-5, torch.ones_like(den), den)
-    z_new = b_lo + (u - c_lo) / den * (b_hi - b_lo)
+    z_new = (b_lo + (u - c_lo) / den * (b_hi - b_lo)).detach()     # ray_utils.py:285: no gradient through the samples
     z_all, order = torch.sort(torch.cat([z, z_new], -1), -1)
     return z_all, z_new, order
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
-PG_ABI_VERSION = 5
+PG_ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):
@@ -45,6 +45,15 @@ _FP = C.c_void_p  # device float*
 class PgTrainDraws(C.Structure):
     """pg_train_draws: the caller's random numbers of one training-mode call."""
     _fields_ = [(k, _FP) for k in ("t_rand", "u_rand", "noise0", "noise1", "ray_noise")]
+
+
+class PgNetParams(C.Structure):
+    """pg_net_params: device pointers of one net's 24 tensors (+ frame codes with the mean row appended)."""
+    _fields_ = [("w", _FP * 24), ("codes", _FP), ("n_codes", C.c_int32)]
+
+
+class PgNetGrads(C.Structure):
+    _fields_ = [("w", _FP * 24), ("codes", _FP)]
 
 
 class PgOutputs(C.Structure):
@@ -103,6 +112,9 @@ PROTOTYPES = {
                                         C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_compose_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pg_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(PgTrainDraws), C.POINTER(PgNetParams), C.POINTER(PgNetParams), C.POINTER(PgOutputs)]),
+    "pg_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, _FP, _FP, _FP, _FP, C.POINTER(PgNetGrads), C.POINTER(PgNetGrads)]),
     "pg_plan_frames": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                  C.POINTER(C.c_int)]),
 }

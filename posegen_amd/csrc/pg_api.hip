@@ -15,6 +15,7 @@
 
 #include "../../include/posegen_hip.h"
 #include "pg_device.h"
+#include "pg_handle.h"
 #include "pg_pack.h"
 
 extern "C" {
@@ -64,54 +65,9 @@ using namespace pgl;
 
 thread_local char g_last_error[512] = "";      // pg_last_error(NULL): per host thread
 
-struct NetState {
-    bool loaded = false;
-    std::vector<std::vector<float>> host;      // 24 tensors, reference order (see header)
-    std::vector<float> codes_host;             // [n_codes+1,16]
-    int n_codes = 0;
-    uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
-    uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the per-ray record kernel (pg_rayrec.hip)
-    uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip): stream,
-    float* d_bias_s = nullptr;                    // ... and its 16-row bias table
-    size_t stream_bytes[PG_PREC_COUNT][2] = {};
-    float* d_bias = nullptr;
-    float* d_codes = nullptr;
-};
-
 }  // namespace
 
-struct pg_handle {
-    pg_config cfg;
-    int device = 0;
-    int n_cu = 256;
-    int clock_khz = 0;
-    char err[512] = "";
-    NetState net[2];
-    float cut[48];
-    float tau[2] = {20.f, 20.f};
-    bool emb_set[2] = {false, false};
-    float* d_cut = nullptr;
-    uint8_t* ws = nullptr;
-    size_t ws_bytes = 0;
-    uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
-    size_t fws_bytes = 0;
-    uint8_t* rec = nullptr;          // per-ray records of the factorised 16-bit path: Y [n + pad, 8 KiB] then (a, b) [n + pad, 768 B]
-    size_t rec_bytes = 0;
-    // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
-    // further device; every handle has a stream and a small pose buffer of its own for that path
-    std::vector<pg_handle*> peers;
-    hipStream_t own_stream = nullptr;
-    float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
-    bool profiling = false;
-    std::vector<hipEvent_t> ev_free;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_aux;      // the record kernel in front of a factorised launch
-    int64_t prof_points = 0;
-};
-
-namespace {
-
-int fail(pg_handle* h, int code, const char* fmt, ...) {
+int pg_fail(pg_handle* h, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -122,12 +78,7 @@ int fail(pg_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
-#define PG_HIP(h, call)                                                                      \
-    do {                                                                                     \
-        hipError_t e_ = (call);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(h, PG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+namespace {
 
 // state setters are forwarded to the sub-handles of a multi-device handle (message of a failing one is kept)
 #define PG_FORWARD(h, call)                                                                  \
@@ -135,7 +86,7 @@ int fail(pg_handle* h, int code, const char* fmt, ...) {
         for (pg_handle* sub_ : (h)->peers) {                                                 \
             pg_handle* hh = sub_;                                                            \
             const int rc_ = (call);                                                          \
-            if (rc_) return fail(h, rc_, "device %d: %s", hh->device, hh->err);              \
+            if (rc_) return pg_fail(h, rc_, "device %d: %s", hh->device, hh->err);              \
         }                                                                                    \
     } while (0)
 
@@ -189,21 +140,21 @@ int ensure_rec(pg_handle* h, int64_t n) {
     if (h->rec) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->rec)); h->rec = nullptr; h->rec_bytes = 0; }
     const size_t want = need + need / 16;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->rec), want);
-    if (e != hipSuccess) return fail(h, PG_ENOMEM, "ray record buffer of %zu bytes failed: %s", want, hipGetErrorString(e));
+    if (e != hipSuccess) return pg_fail(h, PG_ENOMEM, "ray record buffer of %zu bytes failed: %s", want, hipGetErrorString(e));
     h->rec_bytes = want;
     return PG_OK;
 }
 
 int ensure_stream_r(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
-    if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream_r[prec] && ns.d_bias_s && ns.d_vy[prec]) return PG_OK;
     const pgpack::NetTensors t = tensors_of(ns, h->cfg);        // (folds feature_linear into the view layer: milliseconds of host work)
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_stream_r[prec]) {
         std::vector<uint8_t> packed;
         const int rc = pgpack::pack_stream_r(t, prec, packed);
-        if (rc != 0) return fail(h, PG_EINVAL, "16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
+        if (rc != 0) return pg_fail(h, PG_EINVAL, "16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
         PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_r[prec]), packed.size()));
         PG_HIP(h, hipMemcpy(ns.d_stream_r[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
     }
@@ -216,7 +167,7 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     if (!ns.d_vy[prec]) {
         std::vector<uint8_t> vy;
         if (pgpack::pack_vy(t, prec, h->cfg.framecode_ch > 0, vy) != 0)
-            return fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
+            return pg_fail(h, PG_EINVAL, "Y-stage weight packing failed for precision %d", prec);
         PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_vy[prec]), vy.size()));
         PG_HIP(h, hipMemcpy(ns.d_vy[prec], vy.data(), vy.size(), hipMemcpyHostToDevice));
     }
@@ -225,11 +176,11 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
 
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
-    if (!ns.loaded) return fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream[prec][fact]) return PG_OK;
     std::vector<uint8_t> packed;
     const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, fact, packed);
-    if (rc != 0) return fail(h, PG_EINVAL, "weight stream packing failed (%d) for precision %d", rc, prec);
+    if (rc != 0) return pg_fail(h, PG_EINVAL, "weight stream packing failed (%d) for precision %d", rc, prec);
     PG_HIP(h, hipSetDevice(h->device));
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream[prec][fact]), packed.size()));
     PG_HIP(h, hipMemcpy(ns.d_stream[prec][fact], packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -258,16 +209,16 @@ int ensure_ws(pg_handle* h, size_t bytes) {
     if (h->ws) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     const size_t want = bytes + bytes / 8;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->ws), want);
-    if (e != hipSuccess) return fail(h, PG_ENOMEM, "workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+    if (e != hipSuccess) return pg_fail(h, PG_ENOMEM, "workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
     h->ws_bytes = want;
     return PG_OK;
 }
 
 int check_ready(pg_handle* h, bool need_fine) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (!h->net[0].loaded) return fail(h, PG_ESTATE, "coarse network weights not loaded (pg_load_weights)");
-    if (need_fine && !h->net[1].loaded) return fail(h, PG_ESTATE, "fine network weights not loaded (pg_load_weights)");
-    if (!h->emb_set[0] || !h->emb_set[1]) return fail(h, PG_ESTATE, "embedder state not set (pg_set_embedder)");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (!h->net[0].loaded) return pg_fail(h, PG_ESTATE, "coarse network weights not loaded (pg_load_weights)");
+    if (need_fine && !h->net[1].loaded) return pg_fail(h, PG_ESTATE, "fine network weights not loaded (pg_load_weights)");
+    if (!h->emb_set[0] || !h->emb_set[1]) return pg_fail(h, PG_ESTATE, "embedder state not set (pg_set_embedder)");
     return PG_OK;
 }
 
@@ -287,7 +238,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     if (recs && (rc = ensure_rec(h, n))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
-    if (fc && !ns.d_codes) return fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
+    if (fc && !ns.d_codes) return pg_fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
@@ -315,7 +266,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     a.dbg_stage = dbg_stage;
     const int pts = sa ? pg_eval16_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
     if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
-        return fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
+        return pg_fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
     a.n_iters = (int)iters;
     // POSEGEN_MAX_WG (measurement aid): fewer persistent workgroups than CUs, to see how much of a pass's time
@@ -338,7 +289,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         if (h->profiling) { PG_HIP(h, get(x0)); PG_HIP(h, get(x1)); PG_HIP(h, hipEventRecord(x0, static_cast<hipStream_t>(stream))); }
         const int er = pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);
         if (h->profiling) { PG_HIP(h, hipEventRecord(x1, static_cast<hipStream_t>(stream))); h->ev_aux.emplace_back(x0, x1); }
-        if (er) return fail(h, PG_EHIP, "ray record kernel launch failed: %s", hipGetErrorString((hipError_t)er));
+        if (er) return pg_fail(h, PG_EHIP, "ray record kernel launch failed: %s", hipGetErrorString((hipError_t)er));
     }
     if (h->profiling) {
         PG_HIP(h, get(e0));
@@ -354,7 +305,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         h->ev_used.emplace_back(e0, e1);
         h->prof_points += a.n_points;
     }
-    if (e) return fail(h, PG_EHIP, "fused embed+MLP kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "fused embed+MLP kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -367,45 +318,45 @@ int pg_abi_version(void) { return PG_ABI_VERSION; }
 const char* pg_last_error(const pg_handle* h) { return h ? h->err : g_last_error; }
 
 int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_handle** out) {
-    if (!cfg || !out) return fail(nullptr, PG_EINVAL, "pg_create: null argument");
+    if (!cfg || !out) return pg_fail(nullptr, PG_EINVAL, "pg_create: null argument");
     *out = nullptr;
-    if (n_devices < 1 || n_devices > 64) return fail(nullptr, PG_EINVAL, "pg_create: n_devices must be 1..64, got %d", n_devices);
-    if (n_devices > 1 && !device_ids) return fail(nullptr, PG_EINVAL, "pg_create: device_ids required for n_devices > 1");
+    if (n_devices < 1 || n_devices > 64) return pg_fail(nullptr, PG_EINVAL, "pg_create: n_devices must be 1..64, got %d", n_devices);
+    if (n_devices > 1 && !device_ids) return pg_fail(nullptr, PG_EINVAL, "pg_create: device_ids required for n_devices > 1");
     if (cfg->n_joints != J || cfg->multires != LV || cfg->multires_views != LD || cfg->multires_bones != 0 ||
         cfg->net_depth != DEPTH || cfg->net_width != W || cfg->skip_layer != SKIP || cfg->view_width != VW ||
         (cfg->framecode_ch != 0 && cfg->framecode_ch != FC_CH))
-        return fail(nullptr, PG_EINVAL,
+        return pg_fail(nullptr, PG_EINVAL,
                     "pg_create: unsupported architecture (kernels are built for 24 joints, multires 7/4/0, "
                     "8x256 trunk, skip 4, view width 128, frame code 0|16)");
-    if (cfg->precision < 0 || cfg->precision >= PG_PREC_MODES) return fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
+    if (cfg->precision < 0 || cfg->precision >= PG_PREC_MODES) return pg_fail(nullptr, PG_EINVAL, "pg_create: bad precision %d", cfg->precision);
     if (is_x3(cfg->precision) && !x3_allowed())
-        return fail(nullptr, PG_EINVAL, "pg_create: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", cfg->precision);
-    if (cfg->chunk <= 0) return fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
-    if (!(cfg->density_scale > 0.f)) return fail(nullptr, PG_EINVAL, "pg_create: density_scale must be positive");
+        return pg_fail(nullptr, PG_EINVAL, "pg_create: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", cfg->precision);
+    if (cfg->chunk <= 0) return pg_fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
+    if (!(cfg->density_scale > 0.f)) return pg_fail(nullptr, PG_EINVAL, "pg_create: density_scale must be positive");
     pg_handle* h = new (std::nothrow) pg_handle();
-    if (!h) return fail(nullptr, PG_ENOMEM, "pg_create: out of host memory");
+    if (!h) return pg_fail(nullptr, PG_ENOMEM, "pg_create: out of host memory");
     h->cfg = *cfg;
     h->device = device_ids ? device_ids[0] : 0;
     for (int i = 0; i < 48; ++i) h->cut[i] = cfg->cutoff_dist;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) { delete h; return fail(nullptr, PG_EHIP, "pg_create: no HIP device available (%s)", hipGetErrorString(e)); }
-    if (h->device < 0 || h->device >= ndev) { delete h; return fail(nullptr, PG_EINVAL, "pg_create: device %d out of range (%d devices)", cfg ? device_ids ? device_ids[0] : 0 : 0, ndev); }
+    if (e != hipSuccess || ndev <= 0) { delete h; return pg_fail(nullptr, PG_EHIP, "pg_create: no HIP device available (%s)", hipGetErrorString(e)); }
+    if (h->device < 0 || h->device >= ndev) { delete h; return pg_fail(nullptr, PG_EINVAL, "pg_create: device %d out of range (%d devices)", cfg ? device_ids ? device_ids[0] : 0 : 0, ndev); }
     hipDeviceProp_t prop;
     if (hipSetDevice(h->device) != hipSuccess || hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
         delete h;
-        return fail(nullptr, PG_EHIP, "pg_create: cannot query device");
+        return pg_fail(nullptr, PG_EHIP, "pg_create: cannot query device");
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->clock_khz = prop.clockRate;
     if (hipMalloc(reinterpret_cast<void**>(&h->d_cut), 48 * sizeof(float)) != hipSuccess) {
         delete h;
-        return fail(nullptr, PG_ENOMEM, "pg_create: device allocation failed");
+        return pg_fail(nullptr, PG_ENOMEM, "pg_create: device allocation failed");
     }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->d_pose), (24 * 16 + 8) * sizeof(float)) != hipSuccess) {
         pg_destroy(h);
-        return fail(nullptr, PG_ENOMEM, "pg_create: stream / pose buffer creation failed");
+        return pg_fail(nullptr, PG_ENOMEM, "pg_create: stream / pose buffer creation failed");
     }
     // further devices: one sub-handle each (the same device may be listed twice: two workers on one GPU)
     for (int i = 1; i < n_devices; ++i) {
@@ -432,7 +383,7 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
                     if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
                 }
                 if ((pe != hipSuccess || !can) && !allow_staged) {
-                    const int rc = fail(nullptr, PG_EHIP, "pg_create: device %d cannot access device %d directly (%s); frame gathers would be "
+                    const int rc = pg_fail(nullptr, PG_EHIP, "pg_create: device %d cannot access device %d directly (%s); frame gathers would be "
                                         "staged through the host (set POSEGEN_ALLOW_STAGED_PEER=1 to accept that)", di, dj,
                                         pe != hipSuccess ? hipGetErrorString(pe) : "hipDeviceCanAccessPeer = 0");
                     pg_destroy(h);
@@ -455,6 +406,7 @@ void pg_destroy(pg_handle* h) {
     if (h->d_pose) (void)hipFree(h->d_pose);
     if (h->fws) (void)hipFree(h->fws);
     if (h->rec) (void)hipFree(h->rec);
+    pg_train_release(h);
     for (auto& pr : h->ev_aux) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (NetState& ns : h->net) {
         for (auto& p : ns.d_stream_r) if (p) (void)hipFree(p);
@@ -472,9 +424,9 @@ void pg_destroy(pg_handle* h) {
 }
 
 int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const int64_t* shapes, int n_tensors) {
-    if (!h || !tensors || !shapes) return fail(h, PG_EINVAL, "pg_load_weights: null argument");
-    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_load_weights: which_net must be 0 or 1");
-    if (n_tensors != 24) return fail(h, PG_EINVAL, "pg_load_weights: expected 24 tensors, got %d", n_tensors);
+    if (!h || !tensors || !shapes) return pg_fail(h, PG_EINVAL, "pg_load_weights: null argument");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_load_weights: which_net must be 0 or 1");
+    if (n_tensors != 24) return pg_fail(h, PG_EINVAL, "pg_load_weights: expected 24 tensors, got %d", n_tensors);
     const int vcols = W + CH_D + h->cfg.framecode_ch;
     int64_t want[24][2];
     for (int l = 0; l < DEPTH; ++l) {
@@ -486,9 +438,9 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     want[20][0] = VW; want[20][1] = vcols;  want[21][0] = VW; want[21][1] = 1;
     want[22][0] = 3; want[22][1] = VW;      want[23][0] = 3; want[23][1] = 1;
     for (int i = 0; i < 24; ++i) {
-        if (!tensors[i]) return fail(h, PG_EINVAL, "pg_load_weights: tensor %d is null", i);
+        if (!tensors[i]) return pg_fail(h, PG_EINVAL, "pg_load_weights: tensor %d is null", i);
         if (shapes[2 * i] != want[i][0] || shapes[2 * i + 1] != want[i][1])
-            return fail(h, PG_EINVAL, "pg_load_weights: tensor %d has shape [%lld,%lld], expected [%lld,%lld]", i,
+            return pg_fail(h, PG_EINVAL, "pg_load_weights: tensor %d has shape [%lld,%lld], expected [%lld,%lld]", i,
                         (long long)shapes[2 * i], (long long)shapes[2 * i + 1], (long long)want[i][0], (long long)want[i][1]);
     }
     NetState& ns = h->net[which];
@@ -515,8 +467,8 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
 }
 
 int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_embedder: null handle");
-    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_set_embedder: which must be 0 (embed_fn) or 1 (embeddirs_fn)");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_set_embedder: null handle");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_set_embedder: which must be 0 (embed_fn) or 1 (embeddirs_fn)");
     if (cutoff_dist) std::memcpy(h->cut + 24 * which, cutoff_dist, 24 * sizeof(float));
     h->tau[which] = tau;
     h->emb_set[which] = true;
@@ -527,10 +479,10 @@ int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau
 }
 
 int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) {
-    if (!h || !codes) return fail(h, PG_EINVAL, "pg_set_framecodes: null argument");
-    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_set_framecodes: which_net must be 0 or 1");
-    if (h->cfg.framecode_ch != FC_CH) return fail(h, PG_EINVAL, "pg_set_framecodes: handle was created without frame codes");
-    if (n_codes <= 0) return fail(h, PG_EINVAL, "pg_set_framecodes: n_codes must be positive");
+    if (!h || !codes) return pg_fail(h, PG_EINVAL, "pg_set_framecodes: null argument");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_set_framecodes: which_net must be 0 or 1");
+    if (h->cfg.framecode_ch != FC_CH) return pg_fail(h, PG_EINVAL, "pg_set_framecodes: handle was created without frame codes");
+    if (n_codes <= 0) return pg_fail(h, PG_EINVAL, "pg_set_framecodes: n_codes must be positive");
     NetState& ns = h->net[which];
     ns.codes_host.assign(codes, codes + (size_t)n_codes * FC_CH);
     ns.codes_host.resize((size_t)(n_codes + 1) * FC_CH, 0.f);
@@ -549,10 +501,10 @@ int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) 
 }
 
 int pg_set_precision(pg_handle* h, int precision) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_precision: null handle");
-    if (precision < 0 || precision >= PG_PREC_MODES) return fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_set_precision: null handle");
+    if (precision < 0 || precision >= PG_PREC_MODES) return pg_fail(h, PG_EINVAL, "pg_set_precision: bad precision %d", precision);
     if (is_x3(precision) && !x3_allowed())
-        return fail(h, PG_EINVAL, "pg_set_precision: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", precision);
+        return pg_fail(h, PG_EINVAL, "pg_set_precision: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", precision);
     h->cfg.precision = precision;
     for (int w = 0; w < 2; ++w)
         if (h->net[w].loaded) { int rc = ensure_mode_streams(h, w, precision); if (rc) return rc; }
@@ -561,21 +513,21 @@ int pg_set_precision(pg_handle* h, int precision) {
 }
 
 int pg_set_chunk(pg_handle* h, int chunk) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_set_chunk: null handle");
-    if (chunk <= 0) return fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_set_chunk: null handle");
+    if (chunk <= 0) return pg_fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
     h->cfg.chunk = chunk;
     PG_FORWARD(h, pg_set_chunk(hh, chunk));
     return PG_OK;
 }
 
 int pg_profile_enable(pg_handle* h, int on) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_enable: null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_enable: null handle");
     h->profiling = on != 0;
     return PG_OK;
 }
 
 int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_read_aux: null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_read_aux: null handle");
     PG_HIP(h, hipSetDevice(h->device));
     double ms = 0.0;
     for (auto& pr : h->ev_aux) {
@@ -593,7 +545,7 @@ int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms) {
 }
 
 int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t* n_points) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_profile_read: null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_read: null handle");
     PG_HIP(h, hipSetDevice(h->device));
     double ms = 0.0;
     for (auto& pr : h->ev_used) {
@@ -615,8 +567,8 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
                   int precision, int view_fact, uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes, float* bias_out,
                   int32_t* chunk_bytes) {
-    if (!tensors || !shapes || n_tensors != 24) return fail(nullptr, PG_EINVAL, "pg_debug_pack: need 24 tensors");
-    if (precision < 0 || precision >= PG_PREC_COUNT) return fail(nullptr, PG_EINVAL, "pg_debug_pack: bad precision");
+    if (!tensors || !shapes || n_tensors != 24) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: need 24 tensors");
+    if (precision < 0 || precision >= PG_PREC_COUNT) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: bad precision");
     NetState ns;
     ns.host.assign(24, {});
     for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + shapes[2 * i] * shapes[2 * i + 1]);
@@ -626,11 +578,11 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
     const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed)
                          : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed);
-    if (rc != 0) return fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
+    if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
     if (stream_out) {
-        if ((int64_t)packed.size() > stream_cap) return fail(nullptr, PG_EINVAL, "pg_debug_pack: buffer too small");
+        if ((int64_t)packed.size() > stream_cap) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: buffer too small");
         std::memcpy(stream_out, packed.data(), packed.size());
     }
     if (bias_out) {
@@ -644,7 +596,7 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
 
 int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
                      int precision, uint8_t* out, int64_t cap, int64_t* out_bytes) {
-    if (!tensors || !shapes || n_tensors != 24) return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: need 24 tensors");
+    if (!tensors || !shapes || n_tensors != 24) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: need 24 tensors");
     NetState ns;
     ns.host.assign(24, {});
     for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + shapes[2 * i] * shapes[2 * i + 1]);
@@ -652,24 +604,24 @@ int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_t
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> vy;
     if (pgpack::pack_vy(tensors_of(ns, cfg), precision, framecode_ch > 0, vy) != 0)
-        return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: 16-bit precisions only");
+        return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: 16-bit precisions only");
     if (out_bytes) *out_bytes = (int64_t)vy.size();
     if (out) {
-        if ((int64_t)vy.size() > cap) return fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: buffer too small");
+        if ((int64_t)vy.size() > cap) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: buffer too small");
         std::memcpy(out, vy.data(), vy.size());
     }
     return PG_OK;
 }
 
 int pg_device_info(const pg_handle* h, int32_t* n_cu, int32_t* clock_khz) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_device_info: null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_device_info: null handle");
     if (n_cu) *n_cu = h->n_cu;
     if (clock_khz) *clock_khz = h->clock_khz;
     return PG_OK;
 }
 
 int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double* tflops, double* ms_out) {
-    if (!h || !tflops) return fail(h, PG_EINVAL, "pg_calibrate_mfma: null argument");
+    if (!h || !tflops) return pg_fail(h, PG_EINVAL, "pg_calibrate_mfma: null argument");
     PG_HIP(h, hipSetDevice(h->device));
     int rc = ensure_ws(h, 256);
     if (rc) return rc;
@@ -699,9 +651,9 @@ int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double*
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (err) return fail(h, PG_EHIP, "calibration launch failed: %s", hipGetErrorString((hipError_t)err));
-    if (herr != hipSuccess) return fail(h, PG_EHIP, "calibration kernel failed: %s", hipGetErrorString(herr));
-    if (!(ms > 0.0f) || timed_iters <= 0) return fail(h, PG_EHIP, "calibration measured no time (%.3f ms over %d iterations)", ms, timed_iters);
+    if (err) return pg_fail(h, PG_EHIP, "calibration launch failed: %s", hipGetErrorString((hipError_t)err));
+    if (herr != hipSuccess) return pg_fail(h, PG_EHIP, "calibration kernel failed: %s", hipGetErrorString(herr));
+    if (!(ms > 0.0f) || timed_iters <= 0) return pg_fail(h, PG_EHIP, "calibration measured no time (%.3f ms over %d iterations)", ms, timed_iters);
     const double flop = (double)blocks * 8.0 * (double)timed_iters * 32.0 * 32768.0;
     *tflops = flop / (ms * 1e-3) / 1e12;
     if (ms_out) *ms_out = ms;
@@ -709,7 +661,7 @@ int pg_calibrate_mfma(pg_handle* h, int f16, int lds_fed, double min_ms, double*
 }
 
 int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* mfma_per_group) {
-    if (!h) return fail(nullptr, PG_EINVAL, "pg_query: null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_query: null handle");
     if (precision < 0 || precision >= PG_PREC_MODES) return PG_EINVAL;
     if (precision == PG_PREC_FP16M) precision = PG_PREC_FP16C;      // the pass that produces the returned maps
     const bool fc = h->cfg.framecode_ch > 0;
@@ -736,14 +688,14 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
 
 int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* cyls,
                            int64_t cyl_stride, int n_samples, int flags, float* near_far, float* z) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (n < 0 || !ray_batch || !cyls || !near_far || !z) return fail(h, PG_EINVAL, "pg_stage_sample_coarse: null/negative argument");
-    if (n_samples < 2) return fail(h, PG_EINVAL, "pg_stage_sample_coarse: N_samples must be >= 2");
-    if (cyl_stride != 0 && cyl_stride != 5) return fail(h, PG_EINVAL, "cyl_stride must be 0 or 5");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (n < 0 || !ray_batch || !cyls || !near_far || !z) return pg_fail(h, PG_EINVAL, "pg_stage_sample_coarse: null/negative argument");
+    if (n_samples < 2) return pg_fail(h, PG_EINVAL, "pg_stage_sample_coarse: N_samples must be >= 2");
+    if (cyl_stride != 0 && cyl_stride != 5) return pg_fail(h, PG_EINVAL, "cyl_stride must be 0 or 5");
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, n_samples,
                                     (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, nullptr, stream);
-    if (e) return fail(h, PG_EHIP, "sample_coarse launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "sample_coarse launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -752,9 +704,9 @@ int pg_stage_eval(pg_handle* h, void* stream, int which, int64_t n, int n_sample
                   int dbg_stage) {
     int rc = check_ready(h, which == 1);
     if (rc) return rc;
-    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_stage_eval: which_net must be 0 or 1");
-    if (n < 0 || !ray_batch || !z || !skts || !raw) return fail(h, PG_EINVAL, "pg_stage_eval: null/negative argument");
-    if (pose_stride != 0 && pose_stride != 384) return fail(h, PG_EINVAL, "pose_stride must be 0 or 384");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_stage_eval: which_net must be 0 or 1");
+    if (n < 0 || !ray_batch || !z || !skts || !raw) return pg_fail(h, PG_EINVAL, "pg_stage_eval: null/negative argument");
+    if (pose_stride != 0 && pose_stride != 384) return pg_fail(h, PG_EINVAL, "pose_stride must be 0 or 384");
     if (n == 0) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
     return launch_eval(h, stream, which, n, n_samples, ray_batch, z, skts, pose_stride, cams, raw, dbg, dbg_stage);
@@ -764,9 +716,9 @@ int pg_query_density(pg_handle* h, void* stream, int which, int64_t n_points, co
                      float* raw) {
     int rc = check_ready(h, which == 1);
     if (rc) return rc;
-    if (which < 0 || which > 1) return fail(h, PG_EINVAL, "pg_query_density: which_net must be 0 or 1");
-    if (n_points < 0 || !pts || !skts || !raw) return fail(h, PG_EINVAL, "pg_query_density: null/negative argument");
-    if (n_points > 0x7fffffffLL) return fail(h, PG_EINVAL, "pg_query_density: at most 2^31-1 points per call");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_query_density: which_net must be 0 or 1");
+    if (n_points < 0 || !pts || !skts || !raw) return pg_fail(h, PG_EINVAL, "pg_query_density: null/negative argument");
+    if (n_points > 0x7fffffffLL) return pg_fail(h, PG_EINVAL, "pg_query_density: at most 2^31-1 points per call");
     if (n_points == 0) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
     // one pseudo ray (o = d = 0) that owns all points: the kernels take the pose and the view table
@@ -781,16 +733,16 @@ int pg_query_density(pg_handle* h, void* stream, int which, int64_t n_points, co
 int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, const float* ray_batch, const float* z,
                        const float* raw, float* rgb, float* disp, float* acc, float* alpha, float* weights,
                        int n_importance, float* z_fine) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (n < 0 || !ray_batch || !z || !raw) return fail(h, PG_EINVAL, "pg_stage_composite: null/negative argument");
-    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return fail(h, PG_EINVAL, "pg_stage_composite: N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (n < 0 || !ray_batch || !z || !raw) return pg_fail(h, PG_EINVAL, "pg_stage_composite: null/negative argument");
+    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return pg_fail(h, PG_EINVAL, "pg_stage_composite: N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
     if (n_importance < 0 || n_importance > pg_composite_max_importance() || n_importance == 1)
-        return fail(h, PG_EINVAL, "pg_stage_composite: N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
-    if (n_importance > 0 && n_samples < 3) return fail(h, PG_EINVAL, "importance sampling needs N_samples >= 3");
+        return pg_fail(h, PG_EINVAL, "pg_stage_composite: N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
+    if (n_importance > 0 && n_samples < 3) return pg_fail(h, PG_EINVAL, "importance sampling needs N_samples >= 3");
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_composite(ray_batch, z, raw, n, n_samples, h->cfg.density_scale, h->cfg.rgb_eps, rgb, disp, acc,
                                 alpha, weights, n_importance, z_fine, nullptr, nullptr, nullptr, stream);
-    if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -810,7 +762,7 @@ int pg_render_rays(pg_handle* h, void* stream, int64_t n, const float* ray_batch
 int pg_render_rays_train(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts,
                          int64_t pose_stride, const float* cyls, int64_t cyl_stride, const float* cams, int n_samples,
                          int n_importance, int flags, const pg_train_draws* draws, const pg_outputs* out) {
-    if (!draws) return fail(h, PG_EINVAL, "pg_render_rays_train: null draws (use pg_render_rays for eval mode)");
+    if (!draws) return pg_fail(h, PG_EINVAL, "pg_render_rays_train: null draws (use pg_render_rays for eval mode)");
     return render_rays_impl(h, stream, n, ray_batch, skts, pose_stride, cyls, cyl_stride, cams, n_samples, n_importance,
                             flags, draws, out);
 }
@@ -821,14 +773,14 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
                      int n_importance, int flags, const pg_train_draws* dr, const pg_outputs* out) {
     int rc = check_ready(h, n_importance > 0);
     if (rc) return rc;
-    if (n < 0 || !ray_batch || !skts || !cyls || !out) return fail(h, PG_EINVAL, "pg_render_rays: null/negative argument");
-    if (pose_stride != 0 && pose_stride != 384) return fail(h, PG_EINVAL, "pose_stride must be 0 (shared) or 384 (per ray)");
-    if (cyl_stride != 0 && cyl_stride != 5) return fail(h, PG_EINVAL, "cyl_stride must be 0 (shared) or 5 (per ray)");
-    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return fail(h, PG_EINVAL, "N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
+    if (n < 0 || !ray_batch || !skts || !cyls || !out) return pg_fail(h, PG_EINVAL, "pg_render_rays: null/negative argument");
+    if (pose_stride != 0 && pose_stride != 384) return pg_fail(h, PG_EINVAL, "pose_stride must be 0 (shared) or 384 (per ray)");
+    if (cyl_stride != 0 && cyl_stride != 5) return pg_fail(h, PG_EINVAL, "cyl_stride must be 0 (shared) or 5 (per ray)");
+    if (n_samples < 2 || n_samples > pg_composite_max_samples()) return pg_fail(h, PG_EINVAL, "N_samples %d outside [2,%d]", n_samples, pg_composite_max_samples());
     if (n_importance < 0 || n_importance == 1 || n_importance > pg_composite_max_importance())
-        return fail(h, PG_EINVAL, "N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
+        return pg_fail(h, PG_EINVAL, "N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
     if (n_importance > 0 && n_samples + n_importance > pg_composite_max_samples())
-        return fail(h, PG_EINVAL, "N_samples + N_importance exceeds %d", pg_composite_max_samples());
+        return pg_fail(h, PG_EINVAL, "N_samples + N_importance exceeds %d", pg_composite_max_samples());
     if (n == 0) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -855,11 +807,11 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     {
         int e0 = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, S, (flags & PG_FLAG_LINDISP) ? 1 : 0, nf, zc,
                                          dr ? dr->t_rand : nullptr, stream);
-        if (e0) return fail(h, PG_EHIP, "coarse sampling launch failed: %s", hipGetErrorString((hipError_t)e0));
+        if (e0) return pg_fail(h, PG_EHIP, "coarse sampling launch failed: %s", hipGetErrorString((hipError_t)e0));
     }
     if (rnoise) {       // position noise of the coarse points: rows [:S] of every ray's draws
         int e0 = pg_launch_gather_noise(dr->ray_noise, n, SF, S, nullptr, pn, stream);
-        if (e0) return fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e0));
+        if (e0) return pg_fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e0));
     }
     rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr, 0, nullptr, rnoise ? pn : nullptr, hier);
     if (rc) return rc;
@@ -868,18 +820,18 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
                                 hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
                                 out->weights0 ? out->weights0 : w0, n_importance, hier ? zf : nullptr,
                                 dr ? dr->noise0 : nullptr, dr ? dr->u_rand : nullptr, order, stream);
-    if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     if (hier) {
         if (rnoise) {   // every fine point keeps the noise of the stage it came from, in sorted order (raycasters.py:666-686)
             e = pg_launch_gather_noise(dr->ray_noise, n, SF, SF, order, pn, stream);
-            if (e) return fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e));
+            if (e) return pg_fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e));
         }
         rc = launch_eval(h, stream, 1, n, SF, ray_batch, zf, skts, pose_stride, cams, rawf, nullptr, 0, nullptr, rnoise ? pn : nullptr);
         if (rc) return rc;
         e = pg_launch_composite(ray_batch, zf, rawf, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, out->rgb_map,
                                 out->disp_map, out->acc_map, out->alpha, nullptr, 0, nullptr, dr ? dr->noise1 : nullptr,
                                 nullptr, nullptr, stream);
-        if (e) return fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
+        if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     // optional intermediates
     if (out->near_far) PG_HIP(h, hipMemcpyAsync(out->near_far, nf, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
@@ -894,15 +846,15 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
 int pg_pose_kinematics(pg_handle* h, void* stream, int64_t n_poses, const double* bones, const double* bone_offsets,
                        const int32_t* parents, float* kps, float* skts, double* l2ws) {
     const double* rest_pose = bone_offsets;
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (n_poses < 0 || !bones || !rest_pose || !parents) return fail(h, PG_EINVAL, "pg_pose_kinematics: null/negative argument");
-    if (h->cfg.n_joints != 24) return fail(h, PG_EINVAL, "pg_pose_kinematics: 24-joint SMPL skeleton only");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (n_poses < 0 || !bones || !rest_pose || !parents) return pg_fail(h, PG_EINVAL, "pg_pose_kinematics: null/negative argument");
+    if (h->cfg.n_joints != 24) return pg_fail(h, PG_EINVAL, "pg_pose_kinematics: 24-joint SMPL skeleton only");
     for (int j = 0; j < 24; ++j)
         if (parents[j] < 0 || parents[j] > j || (j > 0 && parents[j] == j))
-            return fail(h, PG_EINVAL, "pg_pose_kinematics: joint %d must come after its parent (%d)", j, parents[j]);
+            return pg_fail(h, PG_EINVAL, "pg_pose_kinematics: joint %d must come after its parent (%d)", j, parents[j]);
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_pose_kinematics(rest_pose, parents, bones, n_poses, kps, skts, l2ws, stream);
-    if (e) return fail(h, PG_EHIP, "pose kinematics kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "pose kinematics kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -913,7 +865,7 @@ struct FrameMaps { float *rgb_map, *disp_map, *acc_map; };      // [n_box,3], [n
 
 int frame_geom(pg_handle* h, int H, int W, const float* c2w, const float* intrinsics, const int* box, float near,
                float far, float cam, pgk::FrameGeom* g) {
-    if (H <= 0 || W <= 0 || !c2w || !intrinsics || !box) return fail(h, PG_EINVAL, "frame: null/non-positive argument");
+    if (H <= 0 || W <= 0 || !c2w || !intrinsics || !box) return pg_fail(h, PG_EINVAL, "frame: null/non-positive argument");
     g->H = H; g->W = W;
     g->tlx = box[0] < 0 ? 0 : box[0]; g->tly = box[1] < 0 ? 0 : box[1];
     const int brx = box[2] > W ? W : box[2], bry = box[3] > H ? H : box[3];
@@ -937,7 +889,7 @@ int frame_ws(pg_handle* h, int64_t n, int64_t n_range, float** rays, float** cam
     if (need > h->fws_bytes) {
         if (h->fws) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->fws)); h->fws = nullptr; h->fws_bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->fws), need + need / 8);
-        if (e != hipSuccess) return fail(h, PG_ENOMEM, "frame workspace allocation of %zu bytes failed", need);
+        if (e != hipSuccess) return pg_fail(h, PG_ENOMEM, "frame workspace allocation of %zu bytes failed", need);
         h->fws_bytes = need + need / 8;
     }
     uint8_t* p = h->fws;
@@ -959,8 +911,8 @@ int frame_ws(pg_handle* h, int64_t n, int64_t n_range, float** rays, float** cam
 int frame_render_range(pg_handle* h, void* stream, const pgk::FrameGeom& g, int64_t r0, int64_t r1, const float* skts,
                        const float* cyl, int n_samples, int n_importance, int flags, FrameMaps* maps, const FrameMaps* ext = nullptr) {
     const int64_t n = (int64_t)g.bw * g.bh;
-    if (r0 < 0 || r1 > n || r0 > r1) return fail(h, PG_EINVAL, "frame range [%lld, %lld) outside the box of %lld rays", (long long)r0, (long long)r1, (long long)n);
-    if (r0 % h->cfg.chunk != 0) return fail(h, PG_EINVAL, "frame range must start on a nanmean group boundary (chunk %d)", h->cfg.chunk);
+    if (r0 < 0 || r1 > n || r0 > r1) return pg_fail(h, PG_EINVAL, "frame range [%lld, %lld) outside the box of %lld rays", (long long)r0, (long long)r1, (long long)n);
+    if (r0 % h->cfg.chunk != 0) return pg_fail(h, PG_EINVAL, "frame range must start on a nanmean group boundary (chunk %d)", h->cfg.chunk);
     PG_HIP(h, hipSetDevice(h->device));
     float *rays, *cams;
     pg_outputs out{};
@@ -973,14 +925,14 @@ int frame_render_range(pg_handle* h, void* stream, const pgk::FrameGeom& g, int6
     else { out.rgb_map = own.rgb_map + r0 * 3; out.disp_map = own.disp_map + r0; out.acc_map = own.acc_map + r0; }
     const bool fc = h->cfg.framecode_ch > 0;
     int e = pg_launch_frame_rays(&g, r0, r1 - r0, rays, fc ? cams : nullptr, stream);
-    if (e) return fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "frame ray kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return pg_render_rays(h, stream, r1 - r0, rays, skts, 0, cyl, 0, fc ? cams : nullptr, n_samples, n_importance, flags, &out);
 }
 
 int frame_compose(pg_handle* h, void* stream, const pgk::FrameGeom& g, const FrameMaps& maps, const float* bg, float base_bg,
                   float* rgb, float* disp, float* acc, uint8_t* rgb8) {
     int e = pg_launch_frame_compose(&g, maps.rgb_map, maps.disp_map, maps.acc_map, bg, base_bg, rgb, disp, acc, rgb8, stream);
-    if (e) return fail(h, PG_EHIP, "frame compose kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "frame compose kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -990,8 +942,8 @@ int pg_render_frame(pg_handle* h, void* stream, int H, int W, const float* c2w, 
                     const int* box, float near, float far, const float* skts, const float* cyl, float cam,
                     int n_samples, int n_importance, int flags, const float* bg, float base_bg,
                     float* rgb, float* disp, float* acc, uint8_t* rgb8) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (!skts || !cyl || !rgb) return fail(h, PG_EINVAL, "pg_render_frame: null argument");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (!skts || !cyl || !rgb) return pg_fail(h, PG_EINVAL, "pg_render_frame: null argument");
     pgk::FrameGeom g{};
     int rc = frame_geom(h, H, W, c2w, intrinsics, box, near, far, cam, &g);
     if (rc) return rc;
@@ -1005,8 +957,8 @@ int pg_render_frame_range(pg_handle* h, void* stream, int H, int W, const float*
                           const int* box, float near, float far, const float* skts, const float* cyl, float cam,
                           int n_samples, int n_importance, int flags, int64_t ray_begin, int64_t ray_end,
                           float* rgb_map, float* disp_map, float* acc_map) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (!skts || !cyl || !rgb_map || !disp_map || !acc_map) return fail(h, PG_EINVAL, "pg_render_frame_range: null argument");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (!skts || !cyl || !rgb_map || !disp_map || !acc_map) return pg_fail(h, PG_EINVAL, "pg_render_frame_range: null argument");
     pgk::FrameGeom g{};
     int rc = frame_geom(h, H, W, c2w, intrinsics, box, near, far, cam, &g);
     if (rc) return rc;
@@ -1016,13 +968,13 @@ int pg_render_frame_range(pg_handle* h, void* stream, int H, int W, const float*
 
 int pg_compose_frame(pg_handle* h, void* stream, int H, int W, const int* box, const float* rgb_map, const float* disp_map,
                      const float* acc_map, const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
-    if (H <= 0 || W <= 0 || !box || !rgb) return fail(h, PG_EINVAL, "pg_compose_frame: null/non-positive argument");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (H <= 0 || W <= 0 || !box || !rgb) return pg_fail(h, PG_EINVAL, "pg_compose_frame: null/non-positive argument");
     pgk::FrameGeom g{};
     const float c2w[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}, intr[4] = {1.f, 1.f, 0.f, 0.f};
     int rc = frame_geom(h, H, W, c2w, intr, box, 0.f, 1.f, -1.f, &g);
     if (rc) return rc;
-    if ((int64_t)g.bw * g.bh > 0 && (!rgb_map || !disp_map || !acc_map)) return fail(h, PG_EINVAL, "pg_compose_frame: null map of a non-empty box");
+    if ((int64_t)g.bw * g.bh > 0 && (!rgb_map || !disp_map || !acc_map)) return pg_fail(h, PG_EINVAL, "pg_compose_frame: null map of a non-empty box");
     PG_HIP(h, hipSetDevice(h->device));
     const FrameMaps maps{const_cast<float*>(rgb_map), const_cast<float*>(disp_map), const_cast<float*>(acc_map)};
     return frame_compose(h, stream, g, maps, bg, base_bg, rgb, disp, acc, rgb8);
@@ -1031,14 +983,14 @@ int pg_compose_frame(pg_handle* h, void* stream, int H, int W, const int* box, c
 int pg_pose_boxes(pg_handle* h, void* stream, int64_t n_poses, const float* kps, const double* w2c, int64_t w2c_stride,
                   const double* ring, double extension, double top_extension, double bot_extension, double fx, double fy,
                   int H, int W, int off_x, int off_y, float* cyls, int32_t* boxes) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
     if (n_poses < 0 || !kps || !w2c || !ring || !cyls || !boxes || H <= 0 || W <= 0)
-        return fail(h, PG_EINVAL, "pg_pose_boxes: null/negative argument");
-    if (w2c_stride != 0 && w2c_stride != 16) return fail(h, PG_EINVAL, "pg_pose_boxes: w2c_stride must be 0 (one camera) or 16");
+        return pg_fail(h, PG_EINVAL, "pg_pose_boxes: null/negative argument");
+    if (w2c_stride != 0 && w2c_stride != 16) return pg_fail(h, PG_EINVAL, "pg_pose_boxes: w2c_stride must be 0 (one camera) or 16");
     PG_HIP(h, hipSetDevice(h->device));
     int e = pg_launch_pose_boxes(kps, n_poses, w2c, w2c_stride, ring, (float)extension, (float)top_extension, (float)bot_extension,
                                  fx, fy, H, W, off_x, off_y, cyls, boxes, stream);
-    if (e) return fail(h, PG_EHIP, "pose box kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (e) return pg_fail(h, PG_EHIP, "pose box kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
 
@@ -1108,12 +1060,12 @@ void plan_frames(const std::vector<int64_t>& n_rays, int G, int chunk, std::vect
 }  // namespace
 
 int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk, int32_t* out_tasks /*[cap,5]*/, int cap, int* n_tasks) {
-    if (n_frames < 0 || !n_rays || n_workers < 1 || chunk < 1 || !n_tasks) return fail(nullptr, PG_EINVAL, "pg_plan_frames: bad argument");
+    if (n_frames < 0 || !n_rays || n_workers < 1 || chunk < 1 || !n_tasks) return pg_fail(nullptr, PG_EINVAL, "pg_plan_frames: bad argument");
     std::vector<FrameTask> t;
     plan_frames(std::vector<int64_t>(n_rays, n_rays + n_frames), n_workers, chunk, &t);
     *n_tasks = (int)t.size();
     if (out_tasks) {
-        if ((int)t.size() > cap) return fail(nullptr, PG_EINVAL, "pg_plan_frames: %zu tasks exceed the capacity %d", t.size(), cap);
+        if ((int)t.size() > cap) return pg_fail(nullptr, PG_EINVAL, "pg_plan_frames: %zu tasks exceed the capacity %d", t.size(), cap);
         for (size_t i = 0; i < t.size(); ++i) {
             out_tasks[5 * i] = t[i].frame; out_tasks[5 * i + 1] = (int32_t)t[i].r0; out_tasks[5 * i + 2] = (int32_t)t[i].r1;
             out_tasks[5 * i + 3] = t[i].worker; out_tasks[5 * i + 4] = t[i].owner;
@@ -1126,9 +1078,9 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
                      float near, float far, const float* skts, const float* cyls, const float* cams, int n_samples,
                      int n_importance, int flags, const float* bg, float base_bg, float* rgbs, float* disps, float* accs,
                      uint8_t* rgb8) {
-    if (!h) return fail(nullptr, PG_EINVAL, "null handle");
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
     if (n_frames < 0 || H <= 0 || W <= 0 || !c2ws || !intrinsics || !boxes || !skts || !cyls || (!rgbs && !rgb8))
-        return fail(h, PG_EINVAL, "pg_render_frames: null/negative argument");
+        return pg_fail(h, PG_EINVAL, "pg_render_frames: null/negative argument");
     if (n_frames == 0) return PG_OK;
     // Worker 0 runs on the primary handle's own stream over the primary's workspaces: everything the caller
     // queued on ITS stream (pg_render_rays / pg_render_frame are asynchronous and use the same buffers) must
@@ -1160,7 +1112,7 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
 
     auto checker = [&](Worker& w) {
         return [&w](hipError_t e, const char* what) {
-            if (e != hipSuccess && w.rc == PG_OK) w.rc = fail(w.h, PG_EHIP, "%s failed on device %d: %s", what, w.h->device, hipGetErrorString(e));
+            if (e != hipSuccess && w.rc == PG_OK) w.rc = pg_fail(w.h, PG_EHIP, "%s failed on device %d: %s", what, w.h->device, hipGetErrorString(e));
             return e == hipSuccess;
         };
     };
@@ -1272,7 +1224,7 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
         (void)hipSetDevice(w.h->device);
         for (float* b : w.bufs) if (b) (void)hipFree(b);
         if (w.d_bg) (void)hipFree(w.d_bg);
-        if (w.rc && rc == PG_OK) rc = (w.h == h) ? w.rc : fail(h, w.rc, "device %d: %s", w.h->device, w.h->err);
+        if (w.rc && rc == PG_OK) rc = (w.h == h) ? w.rc : pg_fail(h, w.rc, "device %d: %s", w.h->device, w.h->err);
     }
     (void)hipSetDevice(h->device);
     return rc;

@@ -1,0 +1,67 @@
+// pg_handle.h -- the renderer handle behind the C ABI (include/posegen_hip.h), shared by the translation units
+// that implement its entry points (pg_api.hip: rendering; pg_train.hip: the training step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <utility>
+#include <vector>
+
+#include "../../include/posegen_hip.h"
+#include "pg_layout.h"
+
+struct NetState {
+    bool loaded = false;
+    std::vector<std::vector<float>> host;      // 24 tensors, reference order (see header)
+    std::vector<float> codes_host;             // [n_codes+1,16]
+    int n_codes = 0;
+    uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
+    uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the per-ray record kernel (pg_rayrec.hip)
+    uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip): stream,
+    float* d_bias_s = nullptr;                    // ... and its 16-row bias table
+    size_t stream_bytes[PG_PREC_COUNT][2] = {};
+    float* d_bias = nullptr;
+    float* d_codes = nullptr;
+};
+
+
+struct pg_handle {
+    pg_config cfg;
+    int device = 0;
+    int n_cu = 256;
+    int clock_khz = 0;
+    char err[512] = "";
+    NetState net[2];
+    float cut[48];
+    float tau[2] = {20.f, 20.f};
+    bool emb_set[2] = {false, false};
+    float* d_cut = nullptr;
+    uint8_t* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
+    size_t fws_bytes = 0;
+    uint8_t* rec = nullptr;          // per-ray records of the factorised 16-bit path: Y [n + pad, 8 KiB] then (a, b) [n + pad, 768 B]
+    size_t rec_bytes = 0;
+    // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
+    // further device; every handle has a stream and a small pose buffer of its own for that path
+    std::vector<pg_handle*> peers;
+    hipStream_t own_stream = nullptr;
+    float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_aux;      // the record kernel in front of a factorised launch
+    int64_t prof_points = 0;
+    void* train = nullptr;           // the training tape (pg_train.hip): activations of the last pg_train_forward
+};
+
+extern "C" void pg_train_release(pg_handle* h);
+
+// records the message (handle and thread-local "last error") and returns `code`
+int pg_fail(pg_handle* h, int code, const char* fmt, ...);
+
+#define PG_HIP(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return pg_fail(h, PG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import anerf_oracle as orc
 from posegen_amd import synthetic as syn
-from tests.helpers import (cfg_from_golden, load_golden, model_for, oracle_cfg,
+from tests.helpers import (cfg_from_golden, golden_draws, load_golden, model_for, oracle_cfg,
                            oracle_render_rays, torch_weights, weights_digest)
 
 RAY_CASES = ["rays_surreal", "rays_allhit", "rays_coarse32", "rays_cfg1", "rays_h36m"]
@@ -122,3 +122,45 @@ def test_flops_per_point_matches_survey():
     assert surreal_config().flops_per_point() == 1_723_648
     assert h36m_config().flops_per_point() == 1_727_744
     assert orc.flops_per_point(orc.OracleConfig()) == 1_723_648
+
+
+def _loss_of(out, target):
+    """Trainer.compute_loss for the shipped surreal config (core/trainer.py:321-383): MSE of rgb + (1 - acc) * 1 against
+    the target, fine + coarse (coarse_weight 1)."""
+    loss = torch.mean((out["rgb_map"] + (1. - out["acc_map"])[..., None] - target) ** 2)
+    if "rgb0" in out:
+        loss = loss + torch.mean((out["rgb0"] + (1. - out["acc0"])[..., None] - target) ** 2)
+    return loss
+
+
+@pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m"])
+def test_oracle_autograd_matches_the_reference_training_gradients(name):
+    """The oracle under torch autograd against the reference's own `loss.backward()` (fixture from
+    tools/gen_golden.py: Trainer-style MSE on a training-mode call with pytest=True draws): every parameter
+    gradient of both nets (+ frame codes) within 1e-4 of its largest entry -- this pins the gradient oracle the
+    HIP backward pass is tested against."""
+    from tools.gen_golden import grad_sample_index
+    g = load_golden(name)
+    cfg = cfg_from_golden(g)
+    wc, wf, tv, td = model_for(cfg, int(g["seed_model"]))
+    tw = lambda w: {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+    twc, twf = tw(wc), tw(wf)
+    ocfg = oracle_cfg(cfg, g["tau_v"], g["tau_d"])
+    cams = torch.tensor(g["cams"]) if "cams" in g else None
+    out = orc.render_rays(torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]), torch.tensor(g["cyl"]), ocfg, twc, twf,
+                          cfg.n_samples, cfg.n_importance, cams=cams, draws=golden_draws(g))
+    loss = _loss_of(out, torch.tensor(g["target"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    n_checked = 0
+    for tag, w in (("coarse", twc), ("fine", twf)):
+        for k, p in w.items():
+            key = k if k != "framecodes.codes.weight" else "framecodes.codes.weight"
+            ref_vals, ref_norm = g[f"gval_{tag}_{key}"], float(g[f"gnorm_{tag}_{key}"])
+            got = p.grad.numpy().reshape(-1)
+            scale = max(float(np.abs(ref_vals).max()), ref_norm / np.sqrt(got.size), 1e-12)
+            err = float(np.abs(got[grad_sample_index(got.size)] - ref_vals).max())
+            assert err <= 1e-4 * scale + 1e-9, (tag, k, err, scale)
+            assert abs(float(np.linalg.norm(got.astype(np.float64))) - ref_norm) <= 1e-4 * ref_norm + 1e-9, (tag, k)
+            n_checked += 1
+    assert n_checked == (50 if cfg.framecode_ch else 48)
