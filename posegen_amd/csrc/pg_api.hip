@@ -26,7 +26,8 @@ int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
 int pg_launch_eval32(const pgd::EvalArgs* a, int precision, int framecode, int grid, void* stream);
 int pg_eval32_points_per_pass(void);
-int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream);
+int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int rec, int grid, void* stream);
+int pg_launch_ray_records_c(const pgd::RecArgs* a, int framecode, int n_cu, void* stream);
 int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
                             int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
@@ -133,8 +134,15 @@ bool use_comp_kernel(int prec, int S, bool points) {
     return allowed && prec == PG_PREC_FP16C && !points && S >= COMP_MIN_S;
 }
 
-int ensure_rec(pg_handle* h, int64_t n) {
-    const size_t need = (size_t)(n + REC_PAD_RAYS) * (REC_Y_BYTES + REC_AB_BYTES);
+// ... and in that kernel's record variant when a ray has >= FACT_MIN_S samples (per-ray records of
+// ray_records_c_kernel instead of the direct view layer); POSEGEN_COMP_REC=0 forces the direct form (A/B).
+bool use_comp_rec(int S) {
+    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_COMP_REC"); return !(e && e[0] == '0'); }();
+    return allowed && S >= FACT_MIN_S;
+}
+
+int ensure_rec(pg_handle* h, int64_t n, int y_bytes) {
+    const size_t need = (size_t)(n + REC_PAD_RAYS) * ((size_t)y_bytes + REC_AB_BYTES);
     if (need <= h->rec_bytes) return PG_OK;
     PG_HIP(h, hipSetDevice(h->device));
     if (h->rec) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->rec)); h->rec = nullptr; h->rec_bytes = 0; }
@@ -174,6 +182,28 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     return PG_OK;
 }
 
+int ensure_stream_cr(pg_handle* h, int which) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (ns.d_stream_cr && ns.d_vyc) return PG_OK;
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    PG_HIP(h, hipSetDevice(h->device));
+    if (!ns.d_stream_cr) {
+        std::vector<uint8_t> packed;
+        const int rc = pgpack::pack_stream(t, PG_PREC_FP16C, h->cfg.framecode_ch > 0, true, packed, nullptr, true);
+        if (rc != 0) return pg_fail(h, PG_EINVAL, "compensated-fp16 record-variant stream packing failed (%d)", rc);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_cr), packed.size()));
+        PG_HIP(h, hipMemcpy(ns.d_stream_cr, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    if (!ns.d_vyc) {
+        std::vector<float> vy;
+        pgpack::pack_vyc(t, h->cfg.framecode_ch > 0, vy);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_vyc), vy.size() * sizeof(float)));
+        PG_HIP(h, hipMemcpy(ns.d_vyc, vy.data(), vy.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return PG_OK;
+}
+
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -194,6 +224,10 @@ int ensure_mode_streams(pg_handle* h, int which, int mode) {
         if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) {       // + the direct kernel's stream (short rays, points)
             const int rc = ensure_stream_r(h, which, prec);
             return rc ? rc : ensure_stream(h, which, prec, false);
+        }
+        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) {     // + the direct form's stream (32 <= S < 64)
+            const int rc = ensure_stream_cr(h, which);
+            if (rc) return rc;
         }
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
     };
@@ -233,25 +267,27 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
     const bool recs = sa && fact;                                 // per-ray records + the 16x16x32 kernel
-    int rc = recs ? ensure_stream_r(h, which, prec) : ensure_stream(h, which, prec, fact);
+    const bool crec = compk && use_comp_rec(S);                   // per-ray records + the record variant of pg_evalc.hip
+    int rc = recs ? ensure_stream_r(h, which, prec) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
-    if (recs && (rc = ensure_rec(h, n))) return rc;
+    const int y_bytes = crec ? RECC_Y_BYTES : REC_Y_BYTES;
+    if ((recs || crec) && (rc = ensure_rec(h, n, y_bytes))) return rc;
     NetState& ns = h->net[which];
     const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return pg_fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = recs ? ns.d_stream_r[prec] : ns.d_stream[prec][fact];
-    a.wy = recs ? ns.d_vy[prec] : nullptr;
+    a.wstream = recs ? ns.d_stream_r[prec] : crec ? ns.d_stream_cr : ns.d_stream[prec][fact];
+    a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : nullptr;
     a.bias = recs ? ns.d_bias_s : ns.d_bias;
-    if (recs) {
+    if (recs || crec) {
         a.rec_y = h->rec;
-        a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES);
+        a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes);
         // the padding rays behind the last record are fetched by the last passes (their values are multiplied by
         // zero weights at most): keep them finite whatever the buffer held before
-        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * REC_Y_BYTES, 0, (size_t)REC_PAD_RAYS * REC_Y_BYTES, static_cast<hipStream_t>(stream)));
-        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * REC_Y_BYTES + (size_t)n * REC_AB_BYTES, 0,
+        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * y_bytes, 0, (size_t)REC_PAD_RAYS * y_bytes, static_cast<hipStream_t>(stream)));
+        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes + (size_t)n * REC_AB_BYTES, 0,
                                  (size_t)REC_PAD_RAYS * REC_AB_BYTES, static_cast<hipStream_t>(stream)));
     }
     a.cutoff = h->d_cut;
@@ -280,14 +316,14 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         if (!h->ev_free.empty()) { ev = h->ev_free.back(); h->ev_free.pop_back(); return hipSuccess; }
         return hipEventCreate(&ev);
     };
-    if (recs) {     // what depends on the ray only, once per ray, in front of the fused kernel (pg_rayrec.hip)
+    if (recs || crec) {     // what depends on the ray only, once per ray, in front of the fused kernel (pg_rayrec.hip)
         pgd::RecArgs ra{};
         ra.rays = rays; ra.skts = skts; ra.cams = cams; ra.codes = a.codes; ra.wy = a.wy;
         ra.rec_ab = const_cast<float*>(a.rec_ab); ra.rec_y = const_cast<uint8_t*>(a.rec_y);
         ra.pose_stride = pose_stride; ra.n_rays = (int)n; ra.n_codes = ns.n_codes;
         hipEvent_t x0 = nullptr, x1 = nullptr;
         if (h->profiling) { PG_HIP(h, get(x0)); PG_HIP(h, get(x1)); PG_HIP(h, hipEventRecord(x0, static_cast<hipStream_t>(stream))); }
-        const int er = pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);
+        const int er = crec ? pg_launch_ray_records_c(&ra, fc, h->n_cu, stream) : pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);
         if (h->profiling) { PG_HIP(h, hipEventRecord(x1, static_cast<hipStream_t>(stream))); h->ev_aux.emplace_back(x0, x1); }
         if (er) return pg_fail(h, PG_EHIP, "ray record kernel launch failed: %s", hipGetErrorString((hipError_t)er));
     }
@@ -298,7 +334,7 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
     }
     int e = recs ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : compk ? pg_launch_evalc(&a, fc, grid, stream)
+          : compk ? pg_launch_evalc(&a, fc, crec, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
         PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
@@ -413,6 +449,8 @@ void pg_destroy(pg_handle* h) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
+        if (ns.d_stream_cr) (void)hipFree(ns.d_stream_cr);
+        if (ns.d_vyc) (void)hipFree(ns.d_vyc);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
     }
@@ -456,6 +494,8 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
         if (ns.d_stream_r[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_r[p])); ns.d_stream_r[p] = nullptr; }
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
+    if (ns.d_stream_cr) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_cr)); ns.d_stream_cr = nullptr; }
+    if (ns.d_vyc) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vyc)); ns.d_vyc = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
@@ -576,8 +616,9 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> packed;
     const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
+    const bool crec = view_fact == 2 && precision == PG_PREC_FP16C;     // record variant of pg_evalc.hip
     const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed)
-                         : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed);
+                         : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed, nullptr, crec);
     if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
@@ -603,8 +644,13 @@ int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_t
     pg_config cfg{};
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> vy;
-    if (pgpack::pack_vy(tensors_of(ns, cfg), precision, framecode_ch > 0, vy) != 0)
-        return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: 16-bit precisions only");
+    if (precision == PG_PREC_FP16C) {       // the fp32 Y-stage weights of ray_records_c_kernel
+        std::vector<float> f;
+        pgpack::pack_vyc(tensors_of(ns, cfg), framecode_ch > 0, f);
+        vy.resize(f.size() * sizeof(float));
+        std::memcpy(vy.data(), f.data(), vy.size());
+    } else if (pgpack::pack_vy(tensors_of(ns, cfg), precision, framecode_ch > 0, vy) != 0)
+        return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: 16-bit and compensated-fp16 precisions only");
     if (out_bytes) *out_bytes = (int64_t)vy.size();
     if (out) {
         if ((int64_t)vy.size() > cap) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: buffer too small");
@@ -672,6 +718,11 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
         if (stream_bytes) *stream_bytes = (int64_t)pgp::R::NCHUNK * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
+        return PG_OK;
+    }
+    if (compk && use_comp_rec(FACT_MIN_S)) {     // record variant of the compensated kernel (the usual case)
+        if (stream_bytes) *stream_bytes = (int64_t)pgp::C::NCHUNK_R * CHUNK_BYTES;
+        if (mfma_per_group) *mfma_per_group = pgp::C::MFMA_PER_GROUP_R;
         return PG_OK;
     }
     if (stream_bytes)

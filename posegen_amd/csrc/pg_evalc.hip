@@ -24,6 +24,8 @@
 // with one wave per SIMD nothing else would overlap that VALU work with the matrix pipe.
 // The weight stream is staged L2 -> LDS by LDS-DMA into the 3 x 32 KiB ring of pg_device.h and read
 // by hand-issued ds_read_b128 four units ahead with counted lgkmcnt waits (pg_eval16_common.h).
+#include <type_traits>
+
 #include "pg_eval16_common.h"
 
 namespace pgd {
@@ -33,12 +35,22 @@ constexpr int NTHR_C = NWAVE_C * 64;
 constexpr int PTS_C = NWAVE_C * 32;
 using VC = f16x8;
 using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
+using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C>;    // record variant: no view-direction segment
 #ifndef PG_NSC
 #define PG_NSC 4
 #endif
 constexpr int NSC = PG_NSC;                   // register sets of the A pipe: reads issued NSC-1 PAIRS of units ahead
 constexpr int LDS_TOTAL_C = LDS_RTAB + MAXR_C * SLOTC_FLOATS * 4;
 static_assert(LDS_TOTAL_C <= 160 * 1024, "LDS budget of one CU");
+// LDS carve-up of the record variant (bytes): the ring, a compacted bias table (pg_layout.h BTC_*), the cutoff
+// table, two (a, b) buffers (this pass / the next) and the Y records of the pass's <= MAXR_CR rays
+constexpr int LDSC_BIAS = PG_RING_SLOTS * CHUNK_BYTES;
+constexpr int LDSC_CUT = LDSC_BIAS + BTC_COUNT * 32 * 4;
+constexpr int LDSC_AB = LDSC_CUT + 48 * 4;
+constexpr int LDSC_Y = LDSC_AB + 2 * LDS_ABC_BYTES;
+constexpr int LDS_TOTAL_CR = LDSC_Y + MAXR_CR * RECC_Y_BYTES;
+static_assert(LDSC_BIAS % 16 == 0 && LDSC_CUT % 16 == 0 && LDSC_AB % 16 == 0 && LDSC_Y % 16 == 0, "LDS alignment");
+static_assert(LDS_TOTAL_CR <= 160 * 1024, "LDS budget of one CU");
 
 // ---- the fp16 pair of a value: x1 = f16(x) (RNE), x2 = f16(x1 + S (x - x1)) ---------------------
 // Both halves come from ONE conversion result: left to hipcc under -ffp-contract=on, the fragment
@@ -78,6 +90,12 @@ __device__ __forceinline__ unsigned conv_b(float ra, float rb, unsigned h, float
             "v_cvt_pk_f16_f32 %0, %1, %2"
             : "=&v"(x2), "=&v"(da), "=&v"(db) : "v"(h), "v"(ra), "v"(rb), "s"(s));
     return x2;
+}
+
+// one LDS-DMA piece (1 KiB, lane-linear) from a wave-uniform source to a wave-uniform LDS address; counted by the
+// chunk entries' vmcnt like the ring's own pieces
+__device__ __forceinline__ void dma_piece_c(const uint8_t* src, uint32_t lds_dst, uint32_t lane16) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane16), "s"(src) : "memory");
 }
 
 struct FragC { unsigned x1[4], x2[4]; };       // one input unit: 8 values per lane as the two MFMA B operands
@@ -264,12 +282,16 @@ __device__ __forceinline__ void joint_values_c(float qx, float qy, float qz, flo
 }
 
 // one input unit already in registers against NO out tiles (x segments: no look-ahead conversion here)
-template <int NO, int TP, typename ST>
-__device__ __forceinline__ void mma_row_c(f32x16* acc, PairPipe<NSC>& p, ST& st, int uu, const FragC& b) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `hook` runs once, right behind the segment's first chunk entry (before that chunk's first refill piece)
+template <int NO, int TP, typename ST, typename HK = NoHook>
+__device__ __forceinline__ void mma_row_c(f32x16* acc, PairPipe<NSC>& p, ST& st, int uu, const FragC& b, const HK& hook = HK()) {
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
         const int P = uu * NO + o;
         pair_begin<TP>(p, st, P);
+        if (P == 0) hook();
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(b.x1), acc[o], 0, 0, 0);
         pair_mid<TP>(p, st, P);
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(b.x2), acc[o], 0, 0, 0);
@@ -289,9 +311,9 @@ __device__ __forceinline__ FragC frag_of(const float* x, float s129) {
 
 // acc += W[:, x-columns] x: the 432-wide density input generated on the fly (X sequence of pg_layout.h).
 // The values of joint jj+1 are computed and split while the units of joint jj go through the matrix pipe.
-template <typename ST>
+template <typename ST, typename HK = NoHook>
 __device__ __forceinline__ void x_segment_c(f32x16* acc, ST& st, const float* ab, float z, const float* cutb,
-                                            float tl, float s129) {
+                                            float tl, float s129, const HK& hook = HK()) {
     PairPipe<NSC> p;
     constexpr int T = pgp::C::XU * NT;
     auto values = [&](int jj, float* x) {
@@ -311,7 +333,7 @@ __device__ __forceinline__ void x_segment_c(f32x16* acc, ST& st, const float* ab
             const int jj = 4 * sb + k;
             const FragC c0 = f0, c1 = f1;
             if (jj + 1 < JH) values(jj + 1, xn);                               // next joint: embedding math ...
-            mma_row_c<NT, T>(acc, p, st, sb * 9 + 2 * k, c0);
+            mma_row_c<NT, T>(acc, p, st, sb * 9 + 2 * k, c0, hook);
             if (jj + 1 < JH) f0 = frag_of(xn, s129);                           // ... and its split, between this joint's rows
             mma_row_c<NT, T>(acc, p, st, sb * 9 + 2 * k + 1, c1);
             if (jj + 1 < JH) f1 = frag_of(xn + 8, s129);
@@ -384,24 +406,58 @@ __device__ __forceinline__ void ray_table_c(const EvalArgs& a, float* rt, int r0
 // TAPS = the debug taps of pg_stage_eval (dbg_stage 0, 7, 9, 10) compiled in: a separate instantiation,
 // launched only when a dump is asked for -- the cold dump blocks (128 live values each) otherwise cost the
 // production kernel 34 spilled registers, and every scratch reload drains the weight DMA (vmcnt(0))
-template <bool FC, bool TAPS>
+// REC = the record variant (rays with >= FACT_MIN_S samples): (a, b) and the view layer's direction part arrive as
+// per-ray records of pg_rayrec.hip (ray_records_c_kernel) and are fetched by LDS-DMA -- no table build, no barriers
+// at the pass boundary, no 64-bit divisions, and the 648-wide view input (336 MFMAs, 11 chunks of weights and its
+// per-point products and splits) becomes <= 32 MFMAs on the point's 24 cutoff weights.
+template <bool FC, bool TAPS, bool REC>
 __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float* bias = reinterpret_cast<float*>(smem + LDS_BIAS);
-    float* cut = reinterpret_cast<float*>(smem + LDS_CUT);
+    float* bias = reinterpret_cast<float*>(smem + (REC ? LDSC_BIAS : LDS_BIAS));
+    float* cut = reinterpret_cast<float*>(smem + (REC ? LDSC_CUT : LDS_CUT));
     float* rtab = reinterpret_cast<float*>(smem + LDS_RTAB);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, pt = lane & 31;
-    StreamC st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u,
-               (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)(smem + LDS_RING), (uint32_t)lane * 16u};
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    using ST = typename std::conditional<REC, StreamCR, StreamC>::type;
+    ST st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u, lds0 + LDS_RING, lane16};
+    // bias tile indices of this variant's table
+    constexpr int TB_ALPHA = REC ? BTC_ALPHA : BT_ALPHA, TB_VIEWF = REC ? BTC_VIEWF : BT_VIEWF, TB_RGB = REC ? BTC_RGB : BT_RGB;
 
-    for (int i = tid; i < BIAS_FLOATS; i += NTHR_C) bias[i] = a.bias[i];
+    if (REC) {
+        for (int i = tid; i < BTC_COUNT * 32; i += NTHR_C) {
+            const int tile = i >> 5;
+            const int src = tile < BTC_ALPHA ? tile : tile == BTC_ALPHA ? BT_ALPHA : tile < BTC_RGB ? BT_VIEWF + (tile - BTC_VIEWF) : BT_RGB;
+            bias[i] = a.bias[src * 32 + (i & 31)];
+        }
+    } else {
+        for (int i = tid; i < BIAS_FLOATS; i += NTHR_C) bias[i] = a.bias[i];
+    }
     // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
     float s129 = (float)COMP_S;
     asm volatile("" : "+s"(s129));              // one SGPR for the whole kernel, not a literal per use
     st.start();
+
+    // record variant: ray bookkeeping without a division per pass (a 64-bit divide is ~150 VALU instructions and
+    // nothing overlaps them with one wave per SIMD): the pass's first point is sample `off0` of ray `r0`, and both
+    // advance by the constant step of the persistent grid
+    const long long step = (long long)PTS_C * gridDim.x;
+    int dq = 0, dr = 0, r0 = 0, off0 = 0, abuf = 0;
+    long long p0 = (long long)blockIdx.x * PTS_C;
+    const uint8_t* rec_ab = reinterpret_cast<const uint8_t*>(a.rec_ab);
+    if (REC) {
+        dq = __builtin_amdgcn_readfirstlane((int)(step / a.S)); dr = __builtin_amdgcn_readfirstlane((int)(step % a.S));
+        r0 = __builtin_amdgcn_readfirstlane((int)(p0 / a.S));
+        off0 = __builtin_amdgcn_readfirstlane((int)(p0 - (long long)r0 * a.S));
+        // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched a pass ahead
+        if ((int)blockIdx.x < a.n_iters && wave < LDS_ABC_BYTES / 1024)
+            dma_piece_c(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSC_AB + wave * 1024, lane16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
 
 #if defined(PG_STAMPS)
     unsigned long long stamps[14];
@@ -411,31 +467,59 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #if defined(PG_STAMPS)
         { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[10] = t_; }
 #endif
-        const long long p0 = (long long)it * PTS_C;
-        const long long plast = min(p0 + PTS_C - 1, a.n_points - 1);
-        const int r0 = (int)(p0 / a.S);
-        const int nr = (int)(plast / a.S) - r0 + 1;
-        lds_barrier();                          // previous pass is done with the table
-        ray_table_c<FC>(a, rtab, r0, nr);
-        lds_barrier();
-
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
-        const int myr = (int)(gpc / a.S) - r0;
-        const float* slot = rtab + myr * SLOTC_FLOATS;
-        const float* ab = opaque_ptr(slot + SLOTC_AB + JH * h * 8);
+        int myr, r0n = 0, off0n = 0;
+        const float* slot = nullptr;
+        const float* ab;
+        const float* tab = nullptr;
+        if (REC) {
+            // point i of the pass is sample off0 + i of ray r0, i.e. (S >= 64, 128 points) at most 2 rays on; points
+            // past the end of the launch (last pass) take the last valid ray
+            const int last = (int)min((long long)PTS_C - 1, a.n_points - 1 - p0);       // wave-uniform
+            const int S1 = a.S, S2 = 2 * a.S;
+            const int tl_ = off0 + last, ti = off0 + wave * 32 + pt;
+            myr = min((ti >= S1) + (ti >= S2), (tl_ >= S1) + (tl_ >= S2));
+            ab = opaque_ptr(reinterpret_cast<const float*>(smem + LDSC_AB + abuf * LDS_ABC_BYTES + myr * REC_AB_BYTES) + JH * h * 8);
+            off0n = off0 + dr; r0n = r0 + dq;
+            if (off0n >= a.S) { off0n -= a.S; ++r0n; }
+        } else {
+            const long long plast = min(p0 + PTS_C - 1, a.n_points - 1);
+            r0 = (int)(p0 / a.S);
+            const int nr = (int)(plast / a.S) - r0 + 1;
+            lds_barrier();                          // previous pass is done with the table
+            ray_table_c<FC>(a, rtab, r0, nr);
+            lds_barrier();
+            myr = (int)(gpc / a.S) - r0;
+            slot = rtab + myr * SLOTC_FLOATS;
+            ab = opaque_ptr(slot + SLOTC_AB + JH * h * 8);
+            tab = opaque_ptr(slot + SLOTC_DTAB + h * DSEQ);
+        }
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
-        const float* tab = opaque_ptr(slot + SLOTC_DTAB + h * DSEQ);
         const float zz = a.z[gpc];
+        // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the (a, b)
+        // buffer of the pass before may be overwritten.  The 4 waves share the 16 pieces of each of this pass's
+        // MAXR_CR Y records, waves 0..2 fetch a piece of the NEXT pass's (a, b); issued before the chunk's refill
+        // pieces, all of it has landed -- and is visible to every wave -- one chunk entry on (in-order vmcnt).
+        auto fetch_records = [&]() {
+            if (!REC) return;
+            constexpr int PW = MAXR_CR * (RECC_Y_BYTES / 1024) / NWAVE_C;      // 12 pieces per wave
+            const uint8_t* ysrc = a.rec_y + (size_t)r0 * RECC_Y_BYTES + wave * (PW * 1024);
+#pragma unroll
+            for (int k = 0; k < PW; ++k) dma_piece_c(ysrc + k * 1024, lds0 + LDSC_Y + (wave * PW + k) * 1024, lane16);
+            if (wave < LDS_ABC_BYTES / 1024)
+                dma_piece_c(rec_ab + (long long)min(r0n, a.n_rays - 1) * REC_AB_BYTES + wave * 1024,
+                            lds0 + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES + wave * 1024, lane16);
+        };
 
         PG_STAMP(1);
         f32x16 accA[NT], accB[NT];
         // ---- layer 0: K = 432 generated on the fly ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + o, h);
-        x_segment_c(accA, st, ab, zz, cutv, tlv, s129);
+        x_segment_c(accA, st, ab, zz, cutv, tlv, s129, fetch_records);
         if (TAPS && a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
             for (int o = 0; o < NT; ++o)
@@ -481,9 +565,9 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         // ---- sigma head and the view layer's trunk part in one segment of 1 + 4 out tiles: feature_linear
         // has no activation and is folded into the view weights on the host (NetTensors::fold) ----
         f32x16 av[NTV + 1];
-        av[0] = load_bias(bias, BT_ALPHA, h);
+        av[0] = load_bias(bias, TB_ALPHA, h);
 #pragma unroll
-        for (int o = 0; o < NTV; ++o) av[1 + o] = load_bias(bias, BT_VIEWF + o, h);
+        for (int o = 0; o < NTV; ++o) av[1 + o] = load_bias(bias, TB_VIEWF + o, h);
         segment_c<NTV + 1, HU, true>(av, st, srcB, s129);
         const float sigma = av[0][0];
         PG_STAMP(7);
@@ -501,13 +585,47 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) a.dbg[gp * W + JH * h + jj] = wd[jj];
             }
-            const float* code = slot + SLOTC_CODE + 8 * h;
-            auto srcD = [&](int u, int e) {
-                if (u == pgp::C::DU) return code[e];                   // frame code rides as one more unit
-                const int k = u < JH * 3 ? u / 3 : (8 * (u - JH * 3) + e) / 3;
-                return k < JH ? tab[u * 8 + e] * wd[k] : 0.0f;
-            };
-            segment_c<NTV, pgp::C::DU + (FC ? 1 : 0), false>(av + 1, st, srcD, s129);
+            if constexpr (REC) {
+                // second stage of the factorised view layer: av += Yc[ray] w, the cutoff weights split like an
+                // activation; k-unit 0 = joints 12 h + 0..7, k-unit 1 = joints 12 h + 8..11 and the frame code
+                // (weight 1, lane half 0) -- vyc_slot_joint.  A wave's 32 points lie on <= 2 rays: one round per
+                // ray with the other ray's points zeroed.
+                float w1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w1[e] = e < JH - 8 ? wd[8 + e] : 0.0f;
+                if (FC && h == 0) w1[JH - 8] = 1.0f;
+                const FragC f0 = frag_of(wd, s129), f1 = frag_of(w1, s129);
+                const int ra = __builtin_amdgcn_readfirstlane(myr);
+                const int rb = __builtin_amdgcn_readlane(myr, 63);
+                for (int ray = ra; ray <= rb; ++ray) {
+                    FragC g0, g1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        g0.x1[q] = myr == ray ? f0.x1[q] : 0u; g0.x2[q] = myr == ray ? f0.x2[q] : 0u;
+                        g1.x1[q] = myr == ray ? f1.x1[q] : 0u; g1.x2[q] = myr == ray ? f1.x2[q] : 0u;
+                    }
+                    const uint8_t* yb = smem + LDSC_Y + ray * RECC_Y_BYTES + lane * 16;
+#pragma unroll
+                    for (int o = 0; o < NTV; ++o) {
+                        const uint4 a00 = *reinterpret_cast<const uint4*>(yb + (o * 4 + 0) * 1024);
+                        const uint4 a01 = *reinterpret_cast<const uint4*>(yb + (o * 4 + 1) * 1024);
+                        const uint4 a10 = *reinterpret_cast<const uint4*>(yb + (o * 4 + 2) * 1024);
+                        const uint4 a11 = *reinterpret_cast<const uint4*>(yb + (o * 4 + 3) * 1024);
+                        av[1 + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, a00), frag_v(g0.x1), av[1 + o], 0, 0, 0);
+                        av[1 + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, a01), frag_v(g0.x2), av[1 + o], 0, 0, 0);
+                        av[1 + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, a10), frag_v(g1.x1), av[1 + o], 0, 0, 0);
+                        av[1 + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, a11), frag_v(g1.x2), av[1 + o], 0, 0, 0);
+                    }
+                }
+            } else {
+                const float* code = slot + SLOTC_CODE + 8 * h;
+                auto srcD = [&](int u, int e) {
+                    if (u == pgp::C::DU) return code[e];                   // frame code rides as one more unit
+                    const int k = u < JH * 3 ? u / 3 : (8 * (u - JH * 3) + e) / 3;
+                    return k < JH ? tab[u * 8 + e] * wd[k] : 0.0f;
+                };
+                segment_c<NTV, pgp::C::DU + (FC ? 1 : 0), false>(av + 1, st, srcD, s129);
+            }
         }
         if (TAPS && a.dbg && a.dbg_stage == 9 && valid) {
 #pragma unroll
@@ -515,7 +633,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         }
         PG_STAMP(8);
         // ---- rgb head ----
-        f32x16 accr = load_bias(bias, BT_RGB, h);
+        f32x16 accr = load_bias(bias, TB_RGB, h);
         auto srcV = [&](int u, int e) { return av[1 + (u >> 1)][8 * (u & 1) + e]; };
         segment_c<1, HU / 2, true>(&accr, st, srcV, s129);
 #if defined(PG_STAMPS_RGB)
@@ -527,6 +645,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
 #endif
+        if (REC) { abuf ^= 1; r0 = r0n; off0 = off0n; }
+        p0 += step;
 #if !defined(PG_STAMPS_RGB)
         PG_STAMP(9);
 #endif
@@ -545,23 +665,31 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <bool FC, bool TAPS>
+template <bool FC, bool TAPS, bool REC>
 static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = evalc_kernel<FC, TAPS>;
+    auto k = evalc_kernel<FC, TAPS, REC>;
+    constexpr int lds = REC ? LDS_TOTAL_CR : LDS_TOTAL_C;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
-    const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(k), LDS_TOTAL_C, attr_done);
+    const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(k), lds, attr_done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_C), LDS_TOTAL_C, stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR_C), lds, stream, a);
     return hipGetLastError();
+}
+
+template <bool REC>
+static hipError_t dispatch_evalc(const EvalArgs& a, int framecode, int grid, hipStream_t s) {
+    if (a.dbg && a.dbg_stage != 99) return framecode ? launch_evalc<true, true, REC>(a, grid, s) : launch_evalc<false, true, REC>(a, grid, s);
+    return framecode ? launch_evalc<true, false, REC>(a, grid, s) : launch_evalc<false, false, REC>(a, grid, s);
 }
 
 }  // namespace pgd
 
-// needs S >= pgl::COMP_MIN_S, rays (no explicit points) and the shape-C stream (pg_pack.cpp)
-extern "C" int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int grid, void* stream) {
+// needs S >= pgl::COMP_MIN_S, rays (no explicit points) and the shape-C stream (pg_pack.cpp); rec: S >= pgl::FACT_MIN_S,
+// the record variant of the stream (pack_stream(..., rec = true)) and the records of ray_records_c_kernel in
+// a.rec_ab / a.rec_y
+extern "C" int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int rec, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a->dbg && a->dbg_stage != 99) return (int)(framecode ? pgd::launch_evalc<true, true>(*a, grid, s) : pgd::launch_evalc<false, true>(*a, grid, s));
-    return (int)(framecode ? pgd::launch_evalc<true, false>(*a, grid, s) : pgd::launch_evalc<false, false>(*a, grid, s));
+    return (int)(rec ? pgd::dispatch_evalc<true>(*a, framecode, grid, s) : pgd::dispatch_evalc<false>(*a, framecode, grid, s));
 }
 
 extern "C" int pg_evalc_points_per_pass(void) { return pgd::PTS_C; }

@@ -191,6 +191,32 @@ constexpr int REC_TILE_RAYS = 32;                 // rays per MFMA tile of the r
 constexpr int LDS_AB_BYTES = 4096;                // one AB buffer in LDS: MAXR_F x 768 = 3840 -> 4 DMA pieces of 1 KiB
 static_assert(MAXR_F * REC_AB_BYTES <= LDS_AB_BYTES && LDS_AB_BYTES / REC_AB_BYTES + 1 <= REC_PAD_RAYS, "AB fetch stays inside the padded array");
 
+// ---- per-ray records of the compensated-fp16 kernel (pg_rayrec.hip writes, pg_evalc.hip reads; >= 64 samples per ray) ----
+// Same idea for PG_PREC_FP16C: (a, b) as above, and the view layer's direction part as A operands of the
+// compensated product (S-1) y1 w1 + y2 w2 (y = Y / S split like a weight, w = the point's cutoff weights split
+// like an activation):
+//   Yc[ray][out tile32 t][k-unit u][plane][lane (h, row)] x 16 B = the 8 joint slots (vyc_slot_joint) of
+//       plane 0: (S-1) f16(y),  plane 1: f16(y1 + S (y - y1)),  y = Y[ray][j][32 t + row] / S,  Y in fp32
+// A 128-point pass touches <= MAXR_CR rays.  The fp32 Y-stage weights are [joint 0..24][VYC_K][128 out] floats.
+constexpr int RECC_Y_BYTES = (VW / 32) * 2 * 2 * 1024;    // 16384
+constexpr int MAXR_CR = 3;
+constexpr int LDS_ABC_BYTES = 3072;               // one AB buffer in LDS: MAXR_CR x 768 = 2304 -> 3 DMA pieces of 1 KiB
+constexpr int VYC_K = 28;                         // 27 view values per joint (16 of the frame code), padded
+constexpr int VYC_FLOATS = (J + 1) * VYC_K * VW;
+// joint whose weight is value e of k-unit u in lane half h of the second-stage B operand (-1 = zero)
+PG_HD constexpr int vyc_slot_joint(int u, int h, int e, bool fc) {
+    if (u == 0) return JH * h + e;
+    if (e < JH - 8) return JH * h + 8 + e;
+    return (fc && h == 0 && e == JH - 8) ? JC : -1;
+}
+static_assert(MAXR_CR * REC_AB_BYTES <= LDS_ABC_BYTES && LDS_ABC_BYTES / REC_AB_BYTES + 1 <= REC_PAD_RAYS && MAXR_CR <= REC_PAD_RAYS,
+              "record fetches stay inside the padded arrays");
+// compacted bias table of the record variant of pg_evalc.hip: L0..L7 (64 tiles), alpha, folded view (4), rgb
+constexpr int BTC_ALPHA = 64;
+constexpr int BTC_VIEWF = 65;
+constexpr int BTC_RGB = 69;
+constexpr int BTC_COUNT = 70;
+
 // bias tiles: L0..L7 (8 each), feature (8), alpha (1), view (4), rgb (1), folded view (4)
 constexpr int BT_LAYER0 = 0;
 constexpr int BT_FEAT = 64;

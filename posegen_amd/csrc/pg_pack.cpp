@@ -95,7 +95,7 @@ void NetTensors::fold() {
     }
 }
 
-static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false) {
+static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false, bool rec = false) {
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
     if (shape == SHAPE_C) {         // compensated fp16 kernel (pg_evalc.hip): k-major everywhere, direct view layer
@@ -105,9 +105,11 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
         s.push_back({MAT_L0 + 5, NT, true, {{SEQ_X, XSEQ, 0}}});
         for (int l = 6; l <= 7; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
         s.push_back({MAT_ALPHA_VIEWF, NTV + 1, true, {hid(0)}});
-        Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
-        if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
-        s.push_back(v);
+        if (!rec) {                 // (record variant: the view directions arrive as per-ray Y records)
+            Segment v{MAT_VIEW, NTV, true, {{SEQ_D, DSEQ, W}}};
+            if (fc) v.inputs.push_back({SEQ_CODE, 8, W + CH_D});
+            s.push_back(v);
+        }
         s.push_back({MAT_RGB, 1, true, {{SEQ_H, VW / 2, 0}}});
         return s;
     }
@@ -134,7 +136,7 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
 }
 
 int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vector<uint8_t>& out,
-                std::vector<int>* seg_chunk_base) {
+                std::vector<int>* seg_chunk_base, bool rec) {
     const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A
                     : (precision == PG_PREC_FP16C && fact) ? SHAPE_C : SHAPE_B;
     const bool is_f32 = precision == PG_PREC_FP32;
@@ -142,13 +144,13 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const bool comp = precision == PG_PREC_FP16C;
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3 || comp;     // two planes per unit
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
-    if (fact && shape != SHAPE_C) return -3;       // only PG_PREC_FP16C has a second program here (16-bit rays with >= 64 samples: pack_stream_r)
+    if ((fact || rec) && shape != SHAPE_C) return -3;       // only PG_PREC_FP16C has a second program here (16-bit rays with >= 64 samples: pack_stream_r)
     if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
     if (seg_chunk_base) seg_chunk_base->clear();
-    for (const Segment& sg : program(shape, fc, fact, split)) {
+    for (const Segment& sg : program(shape, fc, fact, split, rec)) {
         if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
         // flatten the input units of this segment
         struct U { int seq, u, colbase; };
@@ -195,9 +197,19 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
     const size_t nchunk = shape == SHAPE_A ? (size_t)A::NCHUNK
-                        : shape == SHAPE_C ? (size_t)C::NCHUNK : (split ? B::NCHUNK_FOLD : B::NCHUNK);
+                        : shape == SHAPE_C ? (size_t)(rec ? C::NCHUNK_R : C::NCHUNK) : (split ? B::NCHUNK_FOLD : B::NCHUNK);
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
+}
+
+void pack_vyc(const NetTensors& t, bool fc, std::vector<float>& out) {
+    out.assign((size_t)VYC_FLOATS, 0.f);
+    for (int j = 0; j < J + (fc ? 1 : 0); ++j)
+        for (int k = 0; k < VYC_K; ++k) {
+            const int ch = vd_channel(j, k);
+            if (ch < 0) continue;
+            for (int o = 0; o < VW; ++o) out[((size_t)j * VYC_K + k) * VW + o] = t.w(MAT_VIEW, o, W + ch);
+        }
 }
 
 int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& out) {

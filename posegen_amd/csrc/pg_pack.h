@@ -30,8 +30,10 @@ struct NetTensors {
 // Packs the weight stream for `precision`; returns 0, or <0 on an internal layout error.
 // `fact`: for PG_PREC_FP16C, the program of the dedicated kernel pg_evalc.hip (pg_program.h C); the 16-bit
 // precisions' second program (rays with >= 64 samples, pg_eval16r.hip) is pack_stream_r.
+// `rec` (with fact, PG_PREC_FP16C only): the record variant of that kernel -- no view-direction segment, the view
+// directions arrive as per-ray Y records (pack_vyc, pg_rayrec.hip).
 int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
-                std::vector<int>* seg_chunk_base = nullptr);
+                std::vector<int>* seg_chunk_base = nullptr, bool rec = false);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
 // stream and bias table of the 16x16x32 kernel (pg_program.h R, pg_layout.h "small tile")
 int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out);
@@ -39,5 +41,8 @@ void pack_bias_s(const NetTensors& t, std::vector<float>& out);
 // Y-stage weights of the record kernel (pg_rayrec.hip): [wave 8][unit n][64 lanes x 16 B]; unit n of
 // wave w = (joint vy_joint(w, n/2), k-unit n%2) of out tile w&3 as an MFMA B operand.
 int pack_vy(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out);
+// fp32 Y-stage weights of the compensated-fp16 record kernel: [joint 0..24][VYC_K][128 out channels],
+// W_vd[o, (j, k)] for value k = c * 9 + row of joint j (vd_channel), joint 24 = the frame code
+void pack_vyc(const NetTensors& t, bool framecode, std::vector<float>& out);
 
 }  // namespace pgpack

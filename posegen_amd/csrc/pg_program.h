@@ -113,6 +113,9 @@ static_assert(cdiv(DU * NTV, PPC) == CH_VD, "view segment must take the same chu
 constexpr int MFMA_PER_GROUP(bool fc) {
     return 2 * (2 * XU * NT + 7 * HU * NT + HU * (NTV + 1) + (DU + (fc ? 1 : 0)) * NTV + HU / 2);
 }
+// record variant (>= 64 samples per ray): no view-direction segment, its second stage is 2 k-units x NTV tiles per ray
+constexpr int NCHUNK_R = NCHUNK - CH_VD;
+constexpr int MFMA_PER_GROUP_R = 2 * (2 * XU * NT + 7 * HU * NT + HU * (NTV + 1) + HU / 2) + 2 * 2 * NTV;
 }  // namespace C
 
 }  // namespace pgp

@@ -150,6 +150,143 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
     }
 }
 
+// ---- records of the compensated-fp16 kernel (pg_layout.h "per-ray records of the compensated-fp16 kernel") ----
+// Y in plain fp32 FMAs (its error must stay below the 2^-17 of the compensated products that consume it, so no
+// 16-bit MFMA here): a thread owns one out channel, keeps the 27 weights of one joint in registers and runs them
+// against the T tables of its 8 of the block's 16 rays (LDS, broadcast reads); per lane half and k-unit of the second
+// stage's A operand it then splits the 8 joint values like a weight, y = Y / S -> ((S-1) f16(y), f16(y1 + S (y - y1))),
+// and writes the two 16-byte fragments.  The view table uses accurate sincosf for the base angle like the direct
+// form of pg_evalc.hip did (per ray, its cost is nothing).
+constexpr int RECC_SUB = 8;                     // rays per thread
+constexpr int RECC_THREADS = 2 * VW;            // one thread per out channel of the view layer and half of the block's rays
+constexpr int RECC_RAYS = 2 * RECC_SUB;
+constexpr int RECC_TSTRIDE = (J + 1) * VYC_K + 4;       // floats per ray in LDS (704: rays land 4 banks apart)
+
+// Four slots (half a 16-byte fragment) of k-unit u, lane half h of the second stage's A operand for a thread's out
+// channel: the NJ4 joints' weights sit in registers and a ROLLED loop runs them against the thread's RECC_SUB rays
+// (unrolled over the rays, hipcc delays the FMA chains past the table reads of all rays and parks the rows in scratch).
+template <int NJ4>
+__device__ __forceinline__ void recc_quad(const RecArgs& a, const float* wy, const float* tsub, int ray0, int j0, uint8_t* dst0) {
+    float w[NJ4 > 0 ? NJ4 : 1][VYC_K];
+#pragma unroll
+    for (int e = 0; e < NJ4; ++e)
+#pragma unroll
+        for (int k = 0; k < VYC_K; ++k) w[e][k] = wy[((j0 + e) * VYC_K + k) * VW];
+#pragma unroll 1
+    for (int r = 0; r < RECC_SUB; ++r) {
+        float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < NJ4; ++e) {
+            const float4* tp = reinterpret_cast<const float4*>(tsub + r * RECC_TSTRIDE + (j0 + e) * VYC_K);
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < VYC_K / 4; ++q) {
+                const float4 tq = tp[q];
+                s = fmaf(w[e][4 * q], tq.x, s);
+                s = fmaf(w[e][4 * q + 1], tq.y, s);
+                s = fmaf(w[e][4 * q + 2], tq.z, s);
+                s = fmaf(w[e][4 * q + 3], tq.w, s);
+            }
+            y[e] = s;
+        }
+        unsigned short b0[4], b1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = y[e] * (1.0f / (float)COMP_S);
+            asm volatile("" : "+v"(v));         // one rounded value for both halves (no fused convert of the product)
+            const _Float16 y1 = (_Float16)v;
+            const float y1f = (float)y1;
+            const _Float16 y2 = (_Float16)fmaf((float)COMP_S, v - y1f, y1f);
+            const _Float16 ym = (_Float16)((float)(COMP_S - 1) * y1f);
+            __builtin_memcpy(&b0[e], &ym, 2);
+            __builtin_memcpy(&b1[e], &y2, 2);
+        }
+        if (ray0 + r < a.n_rays) {
+            uint8_t* dst = dst0 + (size_t)r * RECC_Y_BYTES;
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)b0[0] | ((unsigned)b0[1] << 16), (unsigned)b0[2] | ((unsigned)b0[3] << 16));
+            *reinterpret_cast<uint2*>(dst + 1024) = make_uint2((unsigned)b1[0] | ((unsigned)b1[1] << 16), (unsigned)b1[2] | ((unsigned)b1[3] << 16));
+        }
+    }
+}
+
+template <bool FC>
+__global__ __launch_bounds__(RECC_THREADS) void ray_records_c_kernel(const RecArgs a) {
+    constexpr int NJ = J + (FC ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float tl[RECC_RAYS * RECC_TSTRIDE];
+    const int tid = threadIdx.x, o = tid & (VW - 1), sub = tid >> 7, t = o >> 5, row = o & 31;
+    const float* wy = reinterpret_cast<const float*>(a.wy) + o;
+    const float* tsub = tl + sub * RECC_SUB * RECC_TSTRIDE;
+    const int n_tiles = (a.n_rays + RECC_RAYS - 1) / RECC_RAYS;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r0 = tile * RECC_RAYS;
+        __syncthreads();                        // the previous tile's table has been read
+        for (int idx = tid; idx < RECC_RAYS * NJ; idx += RECC_THREADS) {
+            const int rr = idx / NJ, j = idx - rr * NJ;
+            const bool live = r0 + rr < a.n_rays;
+            const long long ray = live ? r0 + rr : a.n_rays - 1;
+            float* tv = tl + rr * RECC_TSTRIDE + j * VYC_K;
+            if (j < J) {
+                const float4* sk = reinterpret_cast<const float4*>(a.skts + ray * a.pose_stride + j * 16);
+                const float4 ra = sk[0], rb = sk[1], rc = sk[2];
+                const float* ry = a.rays + ray * 11;
+                const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
+                float e[3];
+                e[0] = fmaf(ra.z, dz, fmaf(ra.y, dy, ra.x * dx));
+                e[1] = fmaf(rb.z, dz, fmaf(rb.y, dy, rb.x * dx));
+                e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
+                if (live) {
+                    float4* ab = reinterpret_cast<float4*>(a.rec_ab + ray * (REC_AB_BYTES / 4) + j * 8);
+                    ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
+                                        fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
+                                        fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
+                    ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
+                }
+                const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float ev = e[c] / den;
+                    float sn, co;
+                    sincosf(ev, &sn, &co);
+                    tv[c * ROWS_D] = ev;
+#pragma unroll
+                    for (int f = 0; f < LD; ++f) {
+                        tv[c * ROWS_D + 1 + 2 * f] = sn;
+                        tv[c * ROWS_D + 2 + 2 * f] = co;
+                        const float s2 = 2.0f * sn * co;
+                        co = (co - sn) * (co + sn);
+                        sn = s2;
+                    }
+                }
+                tv[27] = 0.0f;
+            } else {
+                const float cam = a.cams ? a.cams[ray] : -1.0f;
+                const int ci = cam < 0.0f ? a.n_codes : min((int)cam, a.n_codes - 1);
+#pragma unroll
+                for (int k = 0; k < VYC_K; ++k) tv[k] = k < FC_CH ? a.codes[ci * FC_CH + k] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {           // lane half of the second stage's A operand (vyc_slot_joint)
+            const int ray0 = r0 + sub * RECC_SUB;
+            uint8_t* d0 = a.rec_y + (size_t)ray0 * RECC_Y_BYTES + (t * 4) * 1024 + (h * 32 + row) * 16;
+            recc_quad<4>(a, wy, tsub, ray0, JH * h, d0);                    // k-unit 0: joints 12 h + 0..7
+            recc_quad<4>(a, wy, tsub, ray0, JH * h + 4, d0 + 8);
+            recc_quad<4>(a, wy, tsub, ray0, JH * h + 8, d0 + 2048);         // k-unit 1: joints 12 h + 8..11,
+            if (FC && h == 0) recc_quad<1>(a, wy, tsub, ray0, JC, d0 + 2048 + 8);   // the frame code (half 0 only), zeros
+            else recc_quad<0>(a, wy, tsub, ray0, 0, d0 + 2048 + 8);
+        }
+    }
+}
+
+template <bool FC>
+static hipError_t launch_records_c(const RecArgs& a, int n_cu, hipStream_t stream) {
+    const int n_tiles = (a.n_rays + RECC_RAYS - 1) / RECC_RAYS;
+    const int cap = 8 * n_cu;
+    hipLaunchKernelGGL((ray_records_c_kernel<FC>), dim3(n_tiles < cap ? n_tiles : cap), dim3(RECC_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <typename V, bool FC>
 static hipError_t launch_records(const RecArgs& a, int n_cu, hipStream_t stream) {
     const int n_tiles = (a.n_rays + REC_TILE_RAYS - 1) / REC_TILE_RAYS;
@@ -159,6 +296,13 @@ static hipError_t launch_records(const RecArgs& a, int n_cu, hipStream_t stream)
 }
 
 }  // namespace pgd
+
+extern "C" int pg_launch_ray_records_c(const pgd::RecArgs* a, int framecode, int n_cu, void* stream) {
+    using namespace pgd;
+    if (a->n_rays <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return (int)(framecode ? launch_records_c<true>(*a, n_cu, s) : launch_records_c<false>(*a, n_cu, s));
+}
 
 extern "C" int pg_launch_ray_records(const pgd::RecArgs* a, int fp16, int framecode, int n_cu, void* stream) {
     using namespace pgd;

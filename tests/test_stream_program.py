@@ -64,7 +64,7 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
-    if fact and prec != PREC_FP16C:      # the compensated kernel has no Y stage (direct view layer)
+    if (fact and prec != PREC_FP16C) or fact == 2:      # Y-stage weights (the compensated kernel: record variant only)
         n = C.c_int64()
         rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(n))
         assert rc == 0, lib.pg_last_error(None)
@@ -343,7 +343,7 @@ def emulate_r(stream, bias16, chunk_bytes, prec, x, cfg, fact):
     return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), state["chunk"] + 1
 
 
-def emulate_c(stream, bias, chunk_bytes, x, cfg):
+def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
     """The compensated-fp16 program (pg_program.h C, pg_evalc.hip): every segment k-major, every
     (input unit, out tile) a PAIR of 1-KiB units -- plane 0 = (S-1) f16(W/S) against x1 = f16(x),
     plane 1 = f16(w1 + S (W/S - w1)) against x2 = f16(x1 + S (x - x1)) -- into one accumulator."""
@@ -398,16 +398,51 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg):
         tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
     av = segment(NTV + 1, [(hidden(tiles), HSEQ)], [bias_tile(BT_ALPHA)] + tiles_of(BT_VIEWF, NTV))
     sigma = av[0][0]
-    ins = [(pair_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
-    if cfg.framecode_ch:
-        ins.append((pair_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
-    vt = segment(NTV, ins, av[1:])
+    if rec is None:
+        ins = [(pair_vals(dseq_channel, DSEQ, x[:, 432:1080]), DSEQ)]
+        if cfg.framecode_ch:
+            ins.append((pair_vals(lambda i, h: 8 * h + i, 8, x[:, 1080:1096]), 8))
+        vt = segment(NTV, ins, av[1:])
+    else:
+        # record variant (pg_rayrec.hip ray_records_c_kernel + the second stage of pg_evalc.hip): Y in fp32 from the
+        # [joint][28][128] weights, split like a weight; the point's 24 cutoff weights (+ 1 for the frame code) split
+        # like an activation; slots per vyc_slot_joint
+        tray, wpt, vyc = rec
+        fc = bool(cfg.framecode_ch)
+        wy = vyc.view(np.float32).reshape(J + 1, 28, VW)
+        y = np.zeros((J + 1, VW), dtype=np.float32)
+        for j in range(J + (1 if fc else 0)):
+            acc = np.zeros(VW, dtype=np.float32)
+            for k in range(28):
+                acc = np.float32(wy[j, k] * np.float32(tray[j, k]) + acc) if k < 27 or j == J else acc
+            y[j] = acc
+        ys = (y * np.float32(1.0 / S)).astype(np.float32)
+        y1 = h16(ys)
+        p0 = h16(np.float32(S - 1) * y1)
+        p1 = h16(y1 + np.float32(S) * (ys - y1))
+        vt = av[1:]
+        for u in range(2):
+            a0 = np.zeros((VW, 2, 8), dtype=np.float32)            # [out, h, e]
+            a1 = np.zeros((VW, 2, 8), dtype=np.float32)
+            wv_ = np.zeros((2, 8, 32), dtype=np.float32)           # [h, e, pt]
+            for h in range(2):
+                for e in range(8):
+                    j = vy_slot_joint(u, h, e, fc)
+                    if j < 0:
+                        continue
+                    a0[:, h, e], a1[:, h, e] = p0[j], p1[j]
+                    wv_[h, e] = wpt[:, j] if j < J else 1.0
+            x1 = h16(wv_)
+            x2 = h16(x1 + np.float32(S) * (wv_ - x1))
+            for o in range(NTV):
+                vt[o] += np.einsum("rhe,hep->rp", a0[32 * o:32 * o + 32], x1) + np.einsum("rhe,hep->rp", a1[32 * o:32 * o + 32], x2)
     rgb = segment(1, [(hidden(vt), VW // 2)], [bias_tile(BT_RGB)])[0]
     return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1), wv.chunk + 1
 
 
 @pytest.mark.parametrize("fc", [False, True])
-def test_packed_compensated_stream_reproduces_mlp(fc):
+@pytest.mark.parametrize("rec", [False, True])
+def test_packed_compensated_stream_reproduces_mlp(fc, rec):
     """The fp16c stream as the kernel consumes it (pairs of planes, k-major, every segment on a chunk
     boundary) against the fp32 oracle: the compensation itself is what is tested -- plain fp16 is at
     4e-3 on this input (test below), the pair must be 40x closer."""
@@ -417,20 +452,32 @@ def test_packed_compensated_stream_reproduces_mlp(fc):
         pytest.skip(str(e))
     cfg = h36m_config() if fc else surreal_config()
     w = syn.make_weights(cfg, 3)
-    stream, bias, chunk_bytes, _ = pack(w, cfg, PREC_FP16C, True)
+    stream, bias, chunk_bytes, vyc = pack(w, cfg, PREC_FP16C, 2 if rec else True)
     rng = np.random.RandomState(0)
     x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
     x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)
+    rec_in = None
+    if rec:       # one ray: view inputs = per-point joint weight x per-ray value (the record variant, S >= 64)
+        tray = np.zeros((J + 1, 32), dtype=np.float32)
+        tray[:J, :27] = rng.uniform(-1, 1, size=(J, 27))
+        wpt = rng.uniform(0, 1, size=(32, J)).astype(np.float32)
+        for j in range(J):
+            for k in range(27):
+                x[:, 432 + vd_channel(j, k)] = wpt[:, j] * tray[j, k]
+        rec_in = (tray, wpt, vyc)
     ocfg = oracle_cfg(cfg, 79.6, 79.6)
     tw = {k: torch.tensor(v) for k, v in w.items()}
     if fc:
         idx = rng.randint(0, cfg.n_framecodes, size=(32, 1)).astype(np.float32)
+        if rec:
+            idx[:] = idx[0]                                            # one ray, one frame code
+            rec_in[0][J, :16] = w["framecodes.codes.weight"][int(idx[0, 0])]
         ref = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1)), tw, ocfg).numpy()
         x_em = np.concatenate([x, w["framecodes.codes.weight"][idx[:, 0].astype(int)]], 1)
     else:
         ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
         x_em = x
-    raw, n_chunks = emulate_c(stream, bias, chunk_bytes, x_em, cfg)
+    raw, n_chunks = emulate_c(stream, bias, chunk_bytes, x_em, cfg, rec_in)
     assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
     err = float(np.abs(raw - ref).max())
     print(f"fp16c stream emulation vs fp32 oracle: {err:.2e} (|ref| max {np.abs(ref).max():.2f})")
