@@ -458,6 +458,9 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
     }
+    // record variant: the depth of the next pass's point, fetched a pass ahead (unconditional, clamped index)
+    float nx_z = 0.0f;
+    if (REC && (int)blockIdx.x < a.n_iters) nx_z = a.z[min(p0 + wave * 32 + pt, a.n_points - 1)];
 
 #if defined(PG_STAMPS)
     unsigned long long stamps[14];
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         }
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
-        const float zz = a.z[gpc];
+        const float zz = REC ? nx_z : a.z[gpc];
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the (a, b)
         // buffer of the pass before may be overwritten.  The 4 waves share the 16 pieces of each of this pass's
         // MAXR_CR Y records, waves 0..2 fetch a piece of the NEXT pass's (a, b); issued before the chunk's refill
@@ -633,9 +636,14 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         }
         PG_STAMP(8);
         // ---- rgb head ----
+        if (REC) nx_z = a.z[min(p0 + step + wave * 32 + pt, a.n_points - 1)];       // in flight through the rgb head and the pass boundary
         f32x16 accr = load_bias(bias, TB_RGB, h);
         auto srcV = [&](int u, int e) { return av[1 + (u >> 1)][8 * (u & 1) + e]; };
+#if defined(PG_ABL_NORGB)       // timing ablation only (wrong results): the rgb head's chunk is entered and refilled, its work skipped
+        { PairPipe<NSC> pq; st.enter_split(); for (int i = 0; i < ST::PER; ++i) piece_c(pq, st, i); asm volatile("" :: "v"(av[1][0]), "v"(av[2][0]), "v"(av[3][0]), "v"(av[4][0])); }
+#else
         segment_c<1, HU / 2, true>(&accr, st, srcV, s129);
+#endif
 #if defined(PG_STAMPS_RGB)
         PG_STAMP(9);
 #endif

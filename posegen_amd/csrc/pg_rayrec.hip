@@ -151,71 +151,79 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
 }
 
 // ---- records of the compensated-fp16 kernel (pg_layout.h "per-ray records of the compensated-fp16 kernel") ----
-// Y in plain fp32 FMAs (its error must stay below the 2^-17 of the compensated products that consume it, so no
-// 16-bit MFMA here): a thread owns one out channel, keeps the 27 weights of one joint in registers and runs them
-// against the T tables of its 8 of the block's 16 rays (LDS, broadcast reads); per lane half and k-unit of the second
-// stage's A operand it then splits the 8 joint values like a weight, y = Y / S -> ((S-1) f16(y), f16(y1 + S (y - y1))),
-// and writes the two 16-byte fragments.  The view table uses accurate sincosf for the base angle like the direct
-// form of pg_evalc.hip did (per ray, its cost is nothing).
-constexpr int RECC_SUB = 8;                     // rays per thread
-constexpr int RECC_THREADS = 2 * VW;            // one thread per out channel of the view layer and half of the block's rays
-constexpr int RECC_RAYS = 2 * RECC_SUB;
-constexpr int RECC_TSTRIDE = (J + 1) * VYC_K + 4;       // floats per ray in LDS (704: rays land 4 banks apart)
+// Y in fp32 (its error must stay below the 2^-17 of the compensated products that consume it, so no 16-bit MFMA
+// here): v_mfma_f32_32x32x2_f32 with 32 rays as rows (A = the ray's view table T from LDS, one float per lane),
+// the out channels as columns (B = the fp32 weights [joint][k][out] straight from L2, one coalesced float per lane)
+// and K = 28 = 14 steps per joint.  Wave w owns out tile w and runs the two lane halves of the second stage's A
+// operand (vyc_slot_joint) one after the other; a k-unit's eight joints at a time, then per ray of the C layout the
+// eight values are split like a weight, y = Y / S -> ((S-1) f16(y), f16(y1 + S (y - y1))), one 16-byte fragment per plane.
+// The view table uses accurate sincosf for the base angle like the direct form of pg_evalc.hip (per ray, its cost
+// is nothing).
+constexpr int RECC_THREADS = 256;            // one wave per SIMD: the 128 accumulators of a k-unit need the 512-register budget
+constexpr int RECC_RAYS = 32;
+constexpr int RECC_TSTRIDE = (J + 1) * VYC_K + 1;        // floats per ray in LDS (701, odd: the 32 rays of an A read hit 32 banks)
+constexpr int RECC_LDS = RECC_RAYS * RECC_TSTRIDE * 4;
 
-// Four slots (half a 16-byte fragment) of k-unit u, lane half h of the second stage's A operand for a thread's out
-// channel: the NJ4 joints' weights sit in registers and a ROLLED loop runs them against the thread's RECC_SUB rays
-// (unrolled over the rays, hipcc delays the FMA chains past the table reads of all rays and parks the rows in scratch).
-template <int NJ4>
-__device__ __forceinline__ void recc_quad(const RecArgs& a, const float* wy, const float* tsub, int ray0, int j0, uint8_t* dst0) {
-    float w[NJ4 > 0 ? NJ4 : 1][VYC_K];
+// One k-unit of the second stage's A operand for this wave's out tile and lane half: the joints of its NJ <= 8 slots
+// (slot e < NJ: joint jbase + e, or JC for the LAST slot when `code`), all accumulators live, so that a ray's eight
+// values leave as ONE 16-byte fragment per plane (32 lanes x 16 B contiguous per store; half fragments of 8 bytes
+// ran the 4.3 GB of a 512 x 512 launch at 1.8 TB/s).
+template <int NJ, bool CODE>
+__device__ __forceinline__ void recc_unit(const RecArgs& a, const float* wy, const float* trow, int ray0, int hl, int jbase, uint8_t* dst0) {
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int e = 0; e < NJ4; ++e)
+    for (int e = 0; e < NJ; ++e)
 #pragma unroll
-        for (int k = 0; k < VYC_K; ++k) w[e][k] = wy[((j0 + e) * VYC_K + k) * VW];
-#pragma unroll 1
-    for (int r = 0; r < RECC_SUB; ++r) {
-        float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < 16; ++r) acc[e][r] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < NJ4; ++e) {
-            const float4* tp = reinterpret_cast<const float4*>(tsub + r * RECC_TSTRIDE + (j0 + e) * VYC_K);
-            float s = 0.0f;
+    for (int kk = 0; kk < VYC_K / 2; ++kk) {
+        if (kk % 2 == 0) asm volatile("" ::: "memory");         // operands of two steps in flight, not of all fourteen
 #pragma unroll
-            for (int q = 0; q < VYC_K / 4; ++q) {
-                const float4 tq = tp[q];
-                s = fmaf(w[e][4 * q], tq.x, s);
-                s = fmaf(w[e][4 * q + 1], tq.y, s);
-                s = fmaf(w[e][4 * q + 2], tq.z, s);
-                s = fmaf(w[e][4 * q + 3], tq.w, s);
+        for (int e = 0; e < NJ; ++e) {
+            const int j = (CODE && e == NJ - 1) ? JC : jbase + e;
+            const float av = trow[j * VYC_K + 2 * kk];
+            const float bv = wy[(j * VYC_K + 2 * kk) * VW];
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[e], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ray = ray0 + rho(r, hl);
+        unsigned p0[4], p1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short b0[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * q + i;
+                float v = e < NJ ? acc[e < NJ ? e : 0][r] * (1.0f / (float)COMP_S) : 0.0f;
+                asm volatile("" : "+v"(v));     // one rounded value for both halves (no fused convert of the product)
+                const _Float16 y1 = (_Float16)v;
+                const float y1f = (float)y1;
+                const _Float16 y2 = (_Float16)fmaf((float)COMP_S, v - y1f, y1f);
+                const _Float16 ym = (_Float16)((float)(COMP_S - 1) * y1f);
+                __builtin_memcpy(&b0[i], &ym, 2);
+                __builtin_memcpy(&b1[i], &y2, 2);
             }
-            y[e] = s;
+            p0[q] = (unsigned)b0[0] | ((unsigned)b0[1] << 16);
+            p1[q] = (unsigned)b1[0] | ((unsigned)b1[1] << 16);
         }
-        unsigned short b0[4], b1[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = y[e] * (1.0f / (float)COMP_S);
-            asm volatile("" : "+v"(v));         // one rounded value for both halves (no fused convert of the product)
-            const _Float16 y1 = (_Float16)v;
-            const float y1f = (float)y1;
-            const _Float16 y2 = (_Float16)fmaf((float)COMP_S, v - y1f, y1f);
-            const _Float16 ym = (_Float16)((float)(COMP_S - 1) * y1f);
-            __builtin_memcpy(&b0[e], &ym, 2);
-            __builtin_memcpy(&b1[e], &y2, 2);
-        }
-        if (ray0 + r < a.n_rays) {
-            uint8_t* dst = dst0 + (size_t)r * RECC_Y_BYTES;
-            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)b0[0] | ((unsigned)b0[1] << 16), (unsigned)b0[2] | ((unsigned)b0[3] << 16));
-            *reinterpret_cast<uint2*>(dst + 1024) = make_uint2((unsigned)b1[0] | ((unsigned)b1[1] << 16), (unsigned)b1[2] | ((unsigned)b1[3] << 16));
+        if (ray < a.n_rays) {
+            uint8_t* dst = dst0 + (size_t)rho(r, hl) * RECC_Y_BYTES;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+            *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
         }
     }
 }
 
 template <bool FC>
-__global__ __launch_bounds__(RECC_THREADS) void ray_records_c_kernel(const RecArgs a) {
+__global__ __launch_bounds__(RECC_THREADS, 1) void ray_records_c_kernel(const RecArgs a) {
     constexpr int NJ = J + (FC ? 1 : 0);
-    __shared__ __attribute__((aligned(16))) float tl[RECC_RAYS * RECC_TSTRIDE];
-    const int tid = threadIdx.x, o = tid & (VW - 1), sub = tid >> 7, t = o >> 5, row = o & 31;
-    const float* wy = reinterpret_cast<const float*>(a.wy) + o;
-    const float* tsub = tl + sub * RECC_SUB * RECC_TSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) float tl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = wave, hl = lane >> 5, col = lane & 31;
+    const float* wy = reinterpret_cast<const float*>(a.wy) + hl * VW + 32 * t + col;       // row k = 2 kk + hl, column 32 t + col
+    const float* trow = tl + col * RECC_TSTRIDE + hl;                                       // ray `col` of the tile, value 2 kk + hl
     const int n_tiles = (a.n_rays + RECC_RAYS - 1) / RECC_RAYS;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int r0 = tile * RECC_RAYS;
@@ -267,23 +275,23 @@ __global__ __launch_bounds__(RECC_THREADS) void ray_records_c_kernel(const RecAr
         }
         __syncthreads();
 #pragma unroll 1
-        for (int h = 0; h < 2; ++h) {           // lane half of the second stage's A operand (vyc_slot_joint)
-            const int ray0 = r0 + sub * RECC_SUB;
-            uint8_t* d0 = a.rec_y + (size_t)ray0 * RECC_Y_BYTES + (t * 4) * 1024 + (h * 32 + row) * 16;
-            recc_quad<4>(a, wy, tsub, ray0, JH * h, d0);                    // k-unit 0: joints 12 h + 0..7
-            recc_quad<4>(a, wy, tsub, ray0, JH * h + 4, d0 + 8);
-            recc_quad<4>(a, wy, tsub, ray0, JH * h + 8, d0 + 2048);         // k-unit 1: joints 12 h + 8..11,
-            if (FC && h == 0) recc_quad<1>(a, wy, tsub, ray0, JC, d0 + 2048 + 8);   // the frame code (half 0 only), zeros
-            else recc_quad<0>(a, wy, tsub, ray0, 0, d0 + 2048 + 8);
+        for (int kh = 0; kh < 2; ++kh) {
+            uint8_t* d0 = a.rec_y + (size_t)r0 * RECC_Y_BYTES + (t * 4) * 1024 + (kh * 32 + col) * 16;
+            recc_unit<8, false>(a, wy, trow, r0, hl, JH * kh, d0);                            // k-unit 0: joints 12 kh + 0..7
+            if (FC && kh == 0) recc_unit<JH - 8 + 1, true>(a, wy, trow, r0, hl, JH * kh + 8, d0 + 2048);   // k-unit 1: joints 12 kh + 8..11
+            else recc_unit<JH - 8, false>(a, wy, trow, r0, hl, JH * kh + 8, d0 + 2048);        // (+ the frame code in half 0), zeros
         }
     }
 }
 
 template <bool FC>
 static hipError_t launch_records_c(const RecArgs& a, int n_cu, hipStream_t stream) {
+    auto k = ray_records_c_kernel<FC>;
+    static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
+    const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(k), RECC_LDS, attr_done);
+    if (e != hipSuccess) return e;
     const int n_tiles = (a.n_rays + RECC_RAYS - 1) / RECC_RAYS;
-    const int cap = 8 * n_cu;
-    hipLaunchKernelGGL((ray_records_c_kernel<FC>), dim3(n_tiles < cap ? n_tiles : cap), dim3(RECC_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(k, dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(RECC_THREADS), RECC_LDS, stream, a);
     return hipGetLastError();
 }
 

@@ -1,4 +1,5 @@
-"""Where a pass of the compensated-fp16 kernel (pg_evalc.hip, built with -DPG_STAMPS) spends its cycles."""
+"""Where a pass of the compensated-fp16 kernel (pg_evalc.hip, record variant) spends its time: s_memtime stamps of a
+-DPG_STAMPS build (tools/build_variant.sh stamps_c -DPG_STAMPS with FILE=pg_evalc.hip; POSEGEN_LIB points at it)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,16 +18,13 @@ for rep in range(2):
 torch.cuda.synchronize()
 full = dbg.view(torch.int64).cpu().numpy().reshape(-1)[: 64 * 8 * 16].reshape(64, 8, 16)[:, :4]
 st = full[:, :, :10]
-print("per pass per wave: cycles waiting in vmcnt (weight DMA) %.0f, in s_barrier %.0f" % (full[1:, :, 10].mean(), full[1:, :, 11].mean()))
+print("per pass per wave: cycles waiting in vmcnt %.0f, in s_barrier %.0f" % (full[1:, :, 10].mean(), full[1:, :, 11].mean()))
 print("   by wave: vmcnt", full[1:, :, 10].mean(0).astype(int).tolist(), " barrier", full[1:, :, 11].mean(0).astype(int).tolist())
-rt = (full[1:, :, 13] - full[1:, :, 12]).astype(np.float64)          # 100 MHz ticks per pass
-cyc = (st[1:, :, 9] - st[1:, :, 0]).astype(np.float64)
-print("shader clock while the kernel runs: %.2f GHz (s_memtime / s_memrealtime over a pass, median)" % float(np.median(cyc / rt * 0.1)))
 d = np.diff(st, axis=-1).astype(np.float64)[1:]
-names = ["ray table", "L0 (x)", "L1-4", "L5 hidden", "L5 x", "L6-7", "alpha+view trunk", "view directions", "rgb+store"]
-mf = [0, 432, 1024, 256, 432, 512, 160, 328, 16]
 tot = (st[1:, :, 9] - st[1:, :, 0]).astype(np.float64)
-print("pass total cycles (s_memtime ticks): mean %.0f  min %.0f max %.0f  -> %.1f cycles per MFMA over %d MFMAs" % (tot.mean(), tot.min(), tot.max(), tot.mean() / sum(mf), sum(mf)))
+print("pass total (s_memtime ticks): mean %.0f  min %.0f max %.0f" % (tot.mean(), tot.min(), tot.max()))
+names = ["pass prologue", "L0 (x)", "L1-4", "L5 (h)", "L5 (x)", "L6-7", "alpha + view trunk", "view directions", "rgb + store"]
+mf = [0, 432, 1024, 256, 432, 512, 160, 16, 16]
 for k, nme in enumerate(names):
     m = d[:, :, k].mean()
-    print(f"{nme:18s} {m:9.0f} cycles  {100*m/tot.mean():5.1f}%   mfma {mf[k]:4d} -> {m/max(mf[k],1):6.1f} cyc/mfma (32 = matrix pipe full)")
+    print(f"{nme:20s} {m:9.0f} ticks  {100*m/tot.mean():5.1f}%   mfma {mf[k]:4d} -> {m/max(mf[k],1):6.1f} ticks/mfma")
