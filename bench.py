@@ -221,6 +221,52 @@ class _DryCaster:
     module = property(lambda self: self)
 
 
+def train_step_rate(dev, n_rand=4096, steps=5, warmup=2):
+    """SURVEY 8(f) rank 4, the training step on the HIP path (posegen_amd.train.TrainableRayCaster): N_rand rays of the
+    benchmark frame (run_nerf.py:211 default 32*32*4), 64 + 16 samples, jitter + density noise, the Trainer's MSE loss
+    on both maps (trainer.py:321-383), loss.backward(), Adam -- time per step and the fp32 GEMM rate it implies."""
+    import torch
+    from posegen_amd import surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRayCaster
+    from posegen_amd.train import TrainableRayCaster
+    cfg = surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=dev, precision="fp32")
+    m = TrainableRayCaster(c)
+    m.train()
+    rb, skts, cyl, *_ = full_frame_rays(512, 512, dev)
+    sel = torch.linspace(0, rb.shape[0] - 1, n_rand, device=dev).long()
+    rb = rb[sel].contiguous()
+    target = torch.rand(n_rand, 3, device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999))
+
+    def step():
+        opt.zero_grad()
+        out = m(rb, N_samples=cfg.n_samples, skts=skts, cyls=cyl, N_importance=cfg.n_importance, perturb=1., raw_noise_std=1.)
+        loss = torch.mean((out["rgb_map"] + (1. - out["acc_map"])[..., None] - target) ** 2) \
+            + torch.mean((out["rgb0"] + (1. - out["acc0"])[..., None] - target) ** 2)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    pts = n_rand * (2 * cfg.n_samples + cfg.n_importance)
+    flop = 3.0 * pts * cfg.flops_per_point()
+    m.renderer.close()
+    return {"n_rand": n_rand, "ms_per_step": ms, "rays_per_s": n_rand / (ms * 1e-3), "points_per_step": pts,
+            "gemm_flop_per_step": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": PEAK_TFLOPS["fp32"],
+            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], "dtype": "f32", "loss": float(loss.detach()),
+            "what": "forward with a tape + MSE loss + loss.backward() + Adam on the whole step's wall clock, fp32 "
+                    "(v_mfma_f32_32x32x2_f32 GEMMs), surreal 64+16, perturb=1, raw_noise_std=1; FLOPs = 3 x the forward MLP "
+                    "FLOPs of the step's points (forward, dX and dW GEMMs); embedding and compositing not counted"}
+
+
 def strong_workload(caster, cfg, H, W, frames, group=None):
     """BASELINE config 5's call pattern: `frames` poses at H x W with the reference's bounding-cylinder cull, one
     camera, white background; one step = one dist.render_frames_distributed call (every rank renders its share
@@ -508,6 +554,7 @@ def main():
             "rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / peak, "avg_launch_ms": kms,
             "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
         cast4.renderer.close()
+        result["train_step"] = train_step_rate(dev)
         if not a.no_cpu_baseline:   # BASELINE config 1: 128x128, 32 coarse (+16) samples per ray
             c1 = surreal_config(n_samples=32)
             _, _, _, rb1, sk1, cy1 = full_frame_rays(128, 128, "cpu")

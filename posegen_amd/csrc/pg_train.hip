@@ -37,6 +37,7 @@ int pg_composite_max_importance(void);
 
 namespace pgt {
 using namespace pgl;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int XW = CH_X + CH_D + FC_CH;       // 1096: row of the materialised input (density | view | frame code or zeros)
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     }
 }
 
-// ---- fp32 GEMM: C[M,N] (op)= A[M,K] B[K,N] with element strides, 64 x 64 x 16 tiles, 4 x 4 per thread ------------
+// ---- fp32 GEMM: C[M,N] (op)= A[M,K] B[K,N] with element strides, 64 x 64 x 16 tiles on v_mfma_f32_32x32x2_f32 ------
 // A(m,k) = A[m sam + k sak], B(k,n) = B[k sbk + n sbn]; the template flags say which index is contiguous (coalesced
 // tile loads).  gridDim.z > 1 splits K and adds the partial tiles into C with float atomics (C zeroed by the caller).
 constexpr int GB = 64, GK = 16;
@@ -125,16 +126,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
                                                     const float* __restrict__ B, long long sbk, long long sbn,
                                                     float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags) {
     __shared__ float As[GK][GB + 4], Bs[GK][GB + 4];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int t = threadIdx.x;
+    // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the tile: v_mfma_f32_32x32x2_f32, A lane (row li, k kh), B lane
+    // (k kh, column li), C lane (column li) x 16 rows rho(r, kh)
+    const int lane = t & 63, wv = t >> 6, mq = (wv >> 1) * 32, nq = (wv & 1) * 32, li = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
     const int nz = gridDim.z;
     const int kper = ((K + nz - 1) / nz + GK - 1) / GK * GK;
     const int k0 = blockIdx.z * kper, k1 = min(K, k0 + kper);
-    float acc[4][4];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     for (int kb = k0; kb < k1; kb += GK) {
         if (A_KCONT) {
             const int m = t >> 2, kq = (t & 3) * 4;
@@ -164,33 +166,120 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GK; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = fmaf(a[i], b[jn], acc[i][jn]);
-        }
+        for (int kk = 0; kk < GK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + kh][mq + li], Bs[2 * kk + kh][nq + li], acc, 0, 0, 0);
         __syncthreads();
     }
+    const int n = n0 + nq + li;
+    if (n < N) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= M) continue;
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-            const int n = n0 + tx * 4 + jn;
-            if (n >= N) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mq + rho(r, kh);
+            if (m >= M) continue;
             float* c = C + (long long)m * ldc + n;
-            float v = acc[i][jn];
+            float v = acc[r];
             if (nz > 1) { atomicAdd(c, v); continue; }
             if (flags & GEMM_ACC) v += *c;
             if (bias) v += bias[n];
             if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
             *c = v;
         }
+    }
+}
+
+// ---- the same GEMM for the large shapes (M, N >= 64; every stride and pointer a multiple of 4 floats): 128 x 128 x 16
+// tiles, a wave owns 64 x 64 (2 x 2 MFMA tiles: one LDS read per MFMA), 16-byte global loads, the next k-step's
+// operands in flight in registers while the current one is multiplied.
+constexpr int TB = 128;
+
+template <bool KCONT>
+__device__ __forceinline__ void tile_fetch(float4 (&v)[2], const float* __restrict__ P, long long s_row, long long s_k,
+                                           int row0, int rows, int kb, int k1, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONT) {            // 4 consecutive k of one row
+            const int r = idx >> 2, k = kb + (idx & 3) * 4;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)(row0 + r) * s_row + k);
+        } else {                // 4 consecutive rows of one k
+            const int k = kb + (idx >> 5), r = (idx & 31) * 4;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)k * s_k + row0 + r);
+        }
+    }
+}
+
+template <bool KCONT>
+__device__ __forceinline__ void tile_store(float (*T)[TB + 4], const float4 (&v)[2], int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = t + 256 * i;
+        if (KCONT) {
+            const int r = idx >> 2, kq = (idx & 3) * 4;
+            T[kq][r] = v[i].x; T[kq + 1][r] = v[i].y; T[kq + 2][r] = v[i].z; T[kq + 3][r] = v[i].w;
+        } else {
+            *reinterpret_cast<float4*>(&T[idx >> 5][(idx & 31) * 4]) = v[i];
+        }
+    }
+}
+
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
+                                                       const float* __restrict__ B, long long sbk, long long sbn,
+                                                       float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags) {
+    __shared__ __attribute__((aligned(16))) float As[GK][TB + 4], Bs[GK][TB + 4];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6, wm = (wv >> 1) * 64, wn = (wv & 1) * 64, li = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+    const int nz = gridDim.z;
+    const int kper = ((K + nz - 1) / nz + GK - 1) / GK * GK;
+    const int k0 = blockIdx.z * kper, k1 = min(K, k0 + kper);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 va[2], vb[2];
+    tile_fetch<A_KCONT>(va, A, sam, sak, m0, M, k0, k1, t);
+    tile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, k0, k1, t);
+    for (int kb = k0; kb < k1; kb += GK) {
+        tile_store<A_KCONT>(As, va, t);
+        tile_store<B_KCONT>(Bs, vb, t);
+        __syncthreads();
+        tile_fetch<A_KCONT>(va, A, sam, sak, m0, M, kb + GK, k1, t);        // (all zeros past the end)
+        tile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, kb + GK, k1, t);
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; ++kk) {
+            const float a0 = As[2 * kk + kh][wm + li], a1 = As[2 * kk + kh][wm + 32 + li];
+            const float b0 = Bs[2 * kk + kh][wn + li], b1 = Bs[2 * kk + kh][wn + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + rho(r, kh);
+                if (m >= M) continue;
+                float* c = C + (long long)m * ldc + n;
+                float v = acc[i][j][r];
+                if (nz > 1) { atomicAdd(c, v); continue; }
+                if (flags & GEMM_ACC) v += *c;
+                v += bv;
+                if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
+                *c = v;
+            }
     }
 }
 
@@ -322,6 +411,18 @@ inline Tape* tape_of(pg_handle* h) {
 int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const float* A, long long sam, long long sak,
          const float* B, long long sbk, long long sbn, float* C, long long ldc, const float* bias, int flags, int ksplit = 1) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
+    auto al4 = [](const void* p, long long a, long long b) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && a % 4 == 0 && b % 4 == 0; };
+    // (the strides that are not 1 must keep 16-byte alignment of every row / k start; M, N, K multiples of 4)
+    const bool big = M >= 64 && N >= 64 && M % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
+                     al4(A, a_kcont ? sam : sak, 4) && al4(B, b_kcont ? sbn : sbk, 4);
+    if (big && !(a_kcont == false && b_kcont == true)) {
+        const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
+        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
+        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
+        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
+        PG_LAUNCH_CHECK(h, "sgemm128");
+        return PG_OK;
+    }
     const dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, ksplit);
     if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
     else if (a_kcont) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
@@ -343,8 +444,9 @@ int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
 // dW[out,in] += dY[P,out]^T X[P,in] (split-K over the points, atomics: dW zeroed by the caller)
 int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* X, long long ldx,
                  float* dW, long long ldw) {
-    const int tiles = ((out + GB - 1) / GB) * ((in + GB - 1) / GB);
-    int ksplit = (int)std::max<long long>(1, std::min<long long>(1024 / std::max(tiles, 1), (P + 2047) / 2048));
+    const int tb = (out >= 64 && in >= 64) ? TB : GB;            // the tile gemm() will pick
+    const int tiles = ((out + tb - 1) / tb) * ((in + tb - 1) / tb);
+    int ksplit = (int)std::max<long long>(1, std::min<long long>(1024 / std::max(tiles, 1), (P + 1023) / 1024));
     return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2));
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
