@@ -132,6 +132,33 @@ def cpu_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays, what):
                       f"torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}, sel, ref
 
 
+def cpu_train_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model, n_rays=512):
+    """The oracle under torch autograd (the reference's training step restated on the CPU: forward, the Trainer's MSE
+    loss on both maps, loss.backward()) timed on the host cores on a bounded batch."""
+    import torch
+    from oracle import anerf_oracle as orc
+    wc, wf, tv, td = model
+    ocfg = orc.OracleConfig(tau_v=tv, tau_d=td)
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    sel = torch.linspace(0, rb_cpu.shape[0] - 1, n_rays).long()
+    sample = rb_cpu[sel]
+    target = torch.rand(n_rays, 3)
+    tw = lambda w: {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+    dt = 0.0
+    for rep in range(2):            # the first repetition warms the allocator up
+        a, b = tw(wc), tw(wf)
+        t0 = time.time()
+        out = orc.render_rays(sample, skts_cpu, cyl_cpu, ocfg, a, b, cfg.n_samples, cfg.n_importance)
+        loss = torch.mean((out["rgb_map"] + (1. - out["acc_map"])[..., None] - target) ** 2) \
+            + torch.mean((out["rgb0"] + (1. - out["acc0"])[..., None] - target) ** 2)
+        loss.backward()
+        dt = time.time() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} rays of the training batch, oracle forward + loss + backward under torch autograd, "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}
+
+
 def timed_rays(r, dev, rb, skts, cyl, cfg, steps, cams=None):
     """(rays/s, ms/frame, kernel TFLOP/s on algorithmic flops) of `steps` render_rays calls."""
     import torch
@@ -555,6 +582,8 @@ def main():
             "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
         cast4.renderer.close()
         result["train_step"] = train_step_rate(dev)
+        if not a.no_cpu_baseline:
+            result["train_step"]["cpu_baseline"] = cpu_train_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model)
         if not a.no_cpu_baseline:   # BASELINE config 1: 128x128, 32 coarse (+16) samples per ray
             c1 = surreal_config(n_samples=32)
             _, _, _, rb1, sk1, cy1 = full_frame_rays(128, 128, "cpu")
