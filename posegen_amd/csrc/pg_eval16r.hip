@@ -313,6 +313,11 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
 #endif
     for (int it = blockIdx.x; it < a.n_iters; it += gridDim.x) {
         PG_STAMP(0);
+        // a per-pass copy of the lane index: LDS addresses derived from it are recomputed per pass (a few VALU operations)
+        // instead of being hoisted out of the pass loop and spilled -- the kernel sits at exactly 256 registers
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+        const int g_p = lane_p >> 4;
         // rays of the pass's points: point i of the pass is sample off0 + i of ray r0, i.e. (S >= 64, 256 points)
         // at most 4 rays on; points past the end of the launch (last pass) take the last valid ray
         const int last = (int)min((long long)PTS - 1, a.n_points - 1 - p0);                 // wave-uniform
@@ -327,17 +332,17 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             const int i = wave * 32 + 16 * c + col;
             myr[c] = min(ray_of(off0 + i), nrm1);
             zz[c] = nx_z[c];
-            abp[c] = opaque_ptr(reinterpret_cast<const float*>(smem + LDSR_AB + abuf * LDS_AB_BYTES + myr[c] * REC_AB_BYTES) + JG * g * 8);
+            abp[c] = opaque_ptr(reinterpret_cast<const float*>(smem + LDSR_AB + abuf * LDS_AB_BYTES + myr[c] * REC_AB_BYTES) + JG * g_p * 8);
         }
         // the next pass of this workgroup
         const int itn = min(it + (int)gridDim.x, a.n_iters - 1);
         int off0n = off0 + dr, r0n = r0 + dq;
         if (off0n >= a.S) { off0n -= a.S; ++r0n; }
-        const float* cutd = opaque_ptr(cut + J + JG * g);
+        const float* cutd = opaque_ptr(cut + J + JG * g_p);
         const QFromAB q0{abp[0], zz[0]}, q1{abp[1], zz[1]};
         float cutv[JG];                         // the lane group's folded cutoff constants (6 registers)
 #pragma unroll
-        for (int jj = 0; jj < JG; ++jj) cutv[jj] = cut[JG * g + jj];
+        for (int jj = 0; jj < JG; ++jj) cutv[jj] = cut[JG * g_p + jj];
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the
         // (a, b) buffer of the pass before may be overwritten.  Wave w fetches out tile w of this pass's MAXR_F Y
         // records and waves 0..3 a piece of the NEXT pass's (a, b); both are in LDS, and visible, one chunk entry on.
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 q1(jj, qx, qy, qz);
                 wd[1][jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
             }
-            y_apply16<V, FC>(vacc, smem + LDSR_Y, wd, myr, lane);
+            y_apply16<V, FC>(vacc, smem + LDSR_Y, wd, myr, lane_p);
 #pragma unroll
             for (int u = 0; u < NTV16 / 2; ++u)
 #pragma unroll
