@@ -349,7 +349,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         auto fetch_records = [&]() {
             const uint8_t* ysrc = a.rec_y + (size_t)r0 * REC_Y_BYTES + wave * 1024;
 #pragma unroll
-            for (int k = 0; k < MAXR_F; ++k) dma_piece(ysrc + (size_t)k * REC_Y_BYTES, lds0 + LDSR_Y + k * REC_Y_BYTES + wave * 1024, lane16);
+            for (int k = 0; k < MAXR_F; ++k)         // slots past the pass's last ray re-fetch that ray (an L2 hit, not HBM; no branch)
+                dma_piece(ysrc + (size_t)min(k, nrm1) * REC_Y_BYTES, lds0 + LDSR_Y + k * REC_Y_BYTES + wave * 1024, lane16);
             if (wave < LDS_AB_BYTES / 1024)
                 dma_piece(rec_ab + (long long)min(r0n, a.n_rays - 1) * REC_AB_BYTES + wave * 1024,
                           lds0 + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES + wave * 1024, lane16);

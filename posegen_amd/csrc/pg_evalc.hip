@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         const long long gp = p0 + wave * 32 + pt;
         const bool valid = gp < a.n_points;
         const long long gpc = valid ? gp : a.n_points - 1;
-        int myr, r0n = 0, off0n = 0;
+        int myr, r0n = 0, off0n = 0, nrm1 = 0;
         const float* slot = nullptr;
         const float* ab;
         const float* tab = nullptr;
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
             const int last = (int)min((long long)PTS_C - 1, a.n_points - 1 - p0);       // wave-uniform
             const int S1 = a.S, S2 = 2 * a.S;
             const int tl_ = off0 + last, ti = off0 + wave * 32 + pt;
-            myr = min((ti >= S1) + (ti >= S2), (tl_ >= S1) + (tl_ >= S2));
+            nrm1 = (tl_ >= S1) + (tl_ >= S2);
+            myr = min((ti >= S1) + (ti >= S2), nrm1);
             ab = opaque_ptr(reinterpret_cast<const float*>(smem + LDSC_AB + abuf * LDS_ABC_BYTES + myr * REC_AB_BYTES) + JH * h * 8);
             off0n = off0 + dr; r0n = r0 + dq;
             if (off0n >= a.S) { off0n -= a.S; ++r0n; }
@@ -509,9 +510,13 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         auto fetch_records = [&]() {
             if (!REC) return;
             constexpr int PW = MAXR_CR * (RECC_Y_BYTES / 1024) / NWAVE_C;      // 12 pieces per wave
-            const uint8_t* ysrc = a.rec_y + (size_t)r0 * RECC_Y_BYTES + wave * (PW * 1024);
+            constexpr int PR = RECC_Y_BYTES / 1024;                             // 16 pieces per record
+            const uint8_t* ysrc = a.rec_y + (size_t)r0 * RECC_Y_BYTES;
 #pragma unroll
-            for (int k = 0; k < PW; ++k) dma_piece_c(ysrc + k * 1024, lds0 + LDSC_Y + (wave * PW + k) * 1024, lane16);
+            for (int k = 0; k < PW; ++k) {           // slots past the pass's last ray re-fetch that ray (an L2 hit, not HBM; no branch)
+                const int q = wave * PW + k;
+                dma_piece_c(ysrc + (size_t)min(q / PR, nrm1) * RECC_Y_BYTES + (q % PR) * 1024, lds0 + LDSC_Y + q * 1024, lane16);
+            }
             if (wave < LDS_ABC_BYTES / 1024)
                 dma_piece_c(rec_ab + (long long)min(r0n, a.n_rays - 1) * REC_AB_BYTES + wave * 1024,
                             lds0 + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES + wave * 1024, lane16);
