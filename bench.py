@@ -499,16 +499,23 @@ def main():
     # nothing else in the loop, one >= 20 ms launch): `peak` stays the nominal dense figure, this says how
     # much of the gap is the chip's clock management under MFMA load rather than the kernel's stalls.
     if a.prec != "fp32" and world == 1:
-        cal = r.calibrate_mfma(f16=a.prec != "bf16")
+        # the shape of the kernel that ran: 16x16x32 for the 16-bit modes (pg_eval16r.hip), 32x32x16 for the compensated one
+        small = 2 if a.prec in ("bf16", "fp16") else 0
+        shape = "16x16x32" if small else "32x32x16"
+        f16 = a.prec != "bf16"
+        cal = r.calibrate_mfma(f16=f16, lds_fed=small)
         result["roofline"]["sustained_mfma_tflops"] = cal["tflops"]
-        result["roofline"]["sustained_mfma_from"] = (f"bare v_mfma_f32_32x32x16_{'bf16' if a.prec == 'bf16' else 'f16'} loop, "
+        result["roofline"]["sustained_mfma_from"] = (f"bare v_mfma_f32_{shape}_{'f16' if f16 else 'bf16'} loop (the kernel's MFMA shape), "
                                                      f"{cal['ms']:.1f} ms launch on this box (pg_calibrate_mfma)")
         result["roofline"]["executed_frac_of_sustained"] = result["roofline"]["executed_tflops"] / cal["tflops"]
         # the same loop with the A operand of every MFMA read from LDS (one ds_read_b128 per MFMA and wave):
-        # the ceiling of the kernels' structure -- 32 points per wave, weight fragments from the LDS ring
-        cal2 = r.calibrate_mfma(f16=a.prec != "bf16", lds_fed=True)
+        # the ceiling of the kernels' structure -- weight fragments from the LDS ring
+        cal2 = r.calibrate_mfma(f16=f16, lds_fed=small | 1)
         result["roofline"]["sustained_mfma_lds_fed_tflops"] = cal2["tflops"]
         result["roofline"]["executed_frac_of_lds_fed"] = result["roofline"]["executed_tflops"] / cal2["tflops"]
+        if small:       # what the chip sustains on the other shape (round 2's kernel): the reason for the re-layout
+            cal3 = r.calibrate_mfma(f16=f16, lds_fed=0)
+            result["roofline"]["sustained_mfma_32x32x16_tflops"] = cal3["tflops"]
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the

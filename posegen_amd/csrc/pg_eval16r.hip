@@ -24,6 +24,11 @@
 #endif
 #include "pg_eval16_common.h"
 
+// cache policy of the per-ray record fetches (streamed once; must not evict the weight stream from L2)
+#ifndef PG_REC_POLICY
+#define PG_REC_POLICY ""
+#endif
+
 namespace pgd {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -70,7 +75,7 @@ __device__ __forceinline__ V relu_pack16(const f32x4& lo, const f32x4& hi, bool 
 // chunk entries' vmcnt like the ring's own pieces (in-order completion: anything issued before a chunk's refill
 // pieces has landed by the next entry, and is visible to every wave behind that entry's barrier)
 __device__ __forceinline__ void dma_piece(const uint8_t* src, uint32_t lds_dst, uint32_t lane16) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane16), "s"(src) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" PG_REC_POLICY :: "s"(lds_dst), "v"(lane16), "s"(src) : "memory");
 }
 
 // one k-unit (two B fragments, one per column tile) against NO out tiles of a k-major segment
