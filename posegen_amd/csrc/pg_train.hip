@@ -226,8 +226,12 @@ __device__ __forceinline__ void tile_store(float (*T)[TB + 4], const float4 (&v)
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
                                                        const float* __restrict__ B, long long sbk, long long sbn,
-                                                       float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags) {
+                                                       float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                       const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum) {
+    // mask: C(m,n) is zeroed where mask[m ldm + n] <= 0 (the ReLU backward of the layer that consumes C, fused);
+    // rowsum (A m-contiguous only): rowsum[m] += sum_k A(m,k) (the bias gradient beside a weight gradient)
     __shared__ __attribute__((aligned(16))) float As[GK][TB + 4], Bs[GK][TB + 4];
+    float rs = 0.0f;
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6, wm = (wv >> 1) * 64, wn = (wv & 1) * 64, li = lane & 31, kh = lane >> 5;
     const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
@@ -250,6 +254,11 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
         __syncthreads();
         tile_fetch<A_KCONT>(va, A, sam, sak, m0, M, kb + GK, k1, t);        // (all zeros past the end)
         tile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, kb + GK, k1, t);
+        // (the block columns of a tile row share the row sums: k-step s belongs to column s mod gridDim.x)
+        if (!A_KCONT && rowsum && (unsigned)((kb - k0) / GK) % gridDim.x == blockIdx.x && t < TB) {
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk) rs += As[kk][t];
+        }
 #pragma unroll
         for (int kk = 0; kk < GK / 2; ++kk) {
             const float a0 = As[2 * kk + kh][wm + li], a1 = As[2 * kk + kh][wm + 32 + li];
@@ -278,9 +287,11 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
                 if (flags & GEMM_ACC) v += *c;
                 v += bv;
                 if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
+                if (mask && !(mask[(long long)m * ldm + n] > 0.0f)) v = 0.0f;
                 *c = v;
             }
     }
+    if (!A_KCONT && rowsum && t < TB && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
 }
 
 // dH <- dH where H > 0 else 0 (ReLU backward on the stored post-activation)
@@ -409,7 +420,8 @@ inline Tape* tape_of(pg_handle* h) {
 
 // C[M,N] = A B (+ bias, relu, accumulate); ksplit > 1: atomic accumulation into C
 int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const float* A, long long sam, long long sak,
-         const float* B, long long sbk, long long sbn, float* C, long long ldc, const float* bias, int flags, int ksplit = 1) {
+         const float* B, long long sbk, long long sbn, float* C, long long ldc, const float* bias, int flags, int ksplit = 1,
+         const float* mask = nullptr, long long ldm = 0, float* rowsum = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
     auto al4 = [](const void* p, long long a, long long b) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && a % 4 == 0 && b % 4 == 0; };
     // (the strides that are not 1 must keep 16-byte alignment of every row / k start; M, N, K multiples of 4)
@@ -417,18 +429,30 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
                      al4(A, a_kcont ? sam : sak, 4) && al4(B, b_kcont ? sbn : sbk, 4);
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
-        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
-        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
-        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
+        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
+        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
+        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
         PG_LAUNCH_CHECK(h, "sgemm128");
         return PG_OK;
     }
+    // small or unaligned shapes: the 64-tile kernel, then the mask / the row sums as kernels of their own
+    if (mask && (ldc != N || ldm != N)) return pg_fail(h, PG_EINVAL, "ReLU mask behind a strided GEMM result is not supported");
+    if (rowsum && a_kcont) return pg_fail(h, PG_EINVAL, "row sums need the m-contiguous A operand");
     const dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, ksplit);
     if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
     else if (a_kcont) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
     else if (!b_kcont) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
     else return pg_fail(h, PG_EINVAL, "unsupported GEMM operand layout");
     PG_LAUNCH_CHECK(h, "sgemm");
+    if (mask) {
+        const unsigned blocks = (unsigned)std::min<long long>(((long long)M * N + 255) / 256, 8192);
+        hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, C, mask, (long long)M * N);
+        PG_LAUNCH_CHECK(h, "relu_mask");
+    }
+    if (rowsum) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, A, (long long)K, M, sak, rowsum);
+        PG_LAUNCH_CHECK(h, "colsum");
+    }
     return PG_OK;
 }
 // Y[P,out] = X[P,in] W[out,in]^T (+ b, relu, accumulate)        (nn.Linear forward)
@@ -437,17 +461,18 @@ int linear_fwd(pg_handle* h, hipStream_t s, long long P, int out, int in, const 
     return gemm(h, s, true, true, (int)P, out, in, X, ldx, 1, W, 1, ldw, Y, ldy, b, flags);
 }
 // dX[P,in] (+)= dY[P,out] W[out,in]
+// relu_of: the stored post-activation the consumer of dX was ReLU'd to -- dX is zeroed where it is <= 0 (fused ReLU backward)
 int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* W, long long ldw,
-                 float* dX, long long ldx, int flags) {
-    return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags);
+                 float* dX, long long ldx, int flags, const float* relu_of = nullptr) {
+    return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx);
 }
 // dW[out,in] += dY[P,out]^T X[P,in] (split-K over the points, atomics: dW zeroed by the caller)
 int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* X, long long ldx,
-                 float* dW, long long ldw) {
+                 float* dW, long long ldw, float* db = nullptr) {      // db[out] += column sums of dY (the bias gradient, fused)
     const int tb = (out >= 64 && in >= 64) ? TB : GB;            // the tile gemm() will pick
     const int tiles = ((out + tb - 1) / tb) * ((in + tb - 1) / tb);
     int ksplit = (int)std::max<long long>(1, std::min<long long>(1024 / std::max(tiles, 1), (P + 1023) / 1024));
-    return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2));
+    return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2), nullptr, 0, db);
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d, rows, N, ld, out);
@@ -502,9 +527,8 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, const Pass& p, const pg_n
     PG_TRY(colsum(h, s, d_raw, P, 3, 4, g.w[23]));
     PG_TRY(relu_mask(h, s, dG, p.G, P * VW));
     // views_linears.0 on [feature | view embedding (| frame code)]
-    PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols));
+    PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols, g.w[21]));
     PG_TRY(linear_bwd_w(h, s, P, VW, vk, dG, VW, p.X + CH_X, XW, g.w[20] + W, vcols));
-    PG_TRY(colsum(h, s, dG, P, VW, VW, g.w[21]));
     float* dF = t.tmpA;
     PG_TRY(linear_bwd_x(h, s, P, VW, W, dG, VW, w.w[20], vcols, dF, W, 0));
     if (fc && g.codes) {
@@ -515,28 +539,26 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, const Pass& p, const pg_n
     }
     // feature_linear and alpha_linear on the trunk output
     const float* h7 = p.H[DEPTH - 1];
-    PG_TRY(linear_bwd_w(h, s, P, W, W, dF, W, h7, W, g.w[18], W));
-    PG_TRY(colsum(h, s, dF, P, W, W, g.w[19]));
-    float* dH = t.tmpB;
-    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, w.w[18], W, dH, W, 0));
-    PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dH, W, GEMM_ACC));
+    PG_TRY(linear_bwd_w(h, s, P, W, W, dF, W, h7, W, g.w[18], W, g.w[19]));
+    float* dH = t.tmpB;             // dH7 = (alpha's part + feature's part) * [H7 > 0]: the mask rides on the second GEMM
+    PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dH, W, 0));
+    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, w.w[18], W, dH, W, GEMM_ACC, h7));
     PG_TRY(linear_bwd_w(h, s, P, 1, W, d_raw + 3, 4, h7, W, g.w[16], W));
     PG_TRY(colsum(h, s, d_raw + 3, P, 1, 4, g.w[17]));
     // the trunk, back to front: dZ_l = dH_l * [H_l > 0]
     float* other = t.tmpA;
+    // (dH arrives masked: the GEMM that produced it zeroed it where H_l <= 0; the bias gradient rides on a weight-gradient GEMM)
     for (int l = DEPTH - 1; l >= 0; --l) {
-        PG_TRY(relu_mask(h, s, dH, p.H[l], P * W));
-        PG_TRY(colsum(h, s, dH, P, W, W, g.w[2 * l + 1]));
         if (l == 0) {
-            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[0], CH_X));
+            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[0], CH_X, g.w[1]));
         } else if (l == SKIP + 1) {
-            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[2 * l], CH_X + W));
+            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[2 * l], CH_X + W, g.w[2 * l + 1]));
             PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l] + CH_X, CH_X + W));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l] + CH_X, CH_X + W, other, W, 0));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l] + CH_X, CH_X + W, other, W, 0, p.H[l - 1]));
             std::swap(dH, other);
         } else {
-            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l], W));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l], W, other, W, 0));
+            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l], W, g.w[2 * l + 1]));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l], W, other, W, 0, p.H[l - 1]));
             std::swap(dH, other);
         }
     }

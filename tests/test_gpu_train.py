@@ -62,6 +62,41 @@ def test_training_step_gradients_match_the_reference_autograd(name):
     m.renderer.close()
 
 
+def test_training_gradients_of_an_odd_batch_match_the_oracle_autograd():
+    """A batch whose point count is not a multiple of 4 (25 rays x 33 + 7 samples) takes the small-tile GEMM with the
+    ReLU mask and the bias sums as kernels of their own instead of fused into the large-tile GEMM: same gradients,
+    checked against the oracle under torch autograd (itself pinned to the reference's gradients on the fixtures)."""
+    from oracle import anerf_oracle as orc
+    from posegen_amd import surreal_config
+    from posegen_amd.raycaster import HipRayCaster, make_training_draws
+    from posegen_amd.train import TrainableRayCaster
+    from tests.helpers import oracle_cfg
+    g = load_golden("train_grads")
+    cfg = surreal_config(n_samples=33, n_importance=7)
+    wc, wf, tv, td = model_for(cfg, 4)
+    n = 25
+    rb, sk, cy = torch.tensor(g["ray_batch"][:n]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    target = torch.tensor(g["target"][:n])
+    draws = make_training_draws(n, 33, 7, perturb=1., raw_noise_std=1., pytest=True)
+    tw = lambda w: {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+    twc, twf = tw(wc), tw(wf)
+    ref = orc.render_rays(rb, sk, cy, oracle_cfg(cfg, tv, td), twc, twf, 33, 7, draws=draws)
+    _loss_of(ref, target).backward()
+    c = HipRayCaster.from_weights(cfg, wc, wf, float(tv), float(td), device=DEV, precision="fp32")
+    m = TrainableRayCaster(c)
+    m.train()
+    out = m(rb, N_samples=33, skts=sk, cyls=cy, N_importance=7, draws={k: v.to(DEV) for k, v in draws.items()})
+    _loss_of(out, target.to(DEV)).backward()
+    for tag, net, refw in (("coarse", m.network, twc), ("fine", m.network_fine, twf)):
+        for key, p in net.items():
+            k = key.replace("__", ".")
+            r = refw[k].grad.numpy().reshape(-1)
+            got = p.grad.detach().cpu().numpy().reshape(-1)
+            scale = max(float(np.abs(r).max()), float(np.linalg.norm(r)) / np.sqrt(r.size), 1e-12)
+            assert float(np.abs(got - r).max()) <= 2e-4 * scale + 1e-9, (tag, k, float(np.abs(got - r).max()), scale)
+    m.renderer.close()
+
+
 def test_training_loop_lowers_the_loss_and_syncs_the_inference_kernels():
     """`get_grad_vars` + Adam as in the reference (core/raycasters.py:186-228, lrate 5e-4): a few steps on one batch
     lower the loss; after sync_inference_weights() the fused inference kernels render with the trained weights
