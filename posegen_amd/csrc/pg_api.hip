@@ -256,9 +256,9 @@ int check_ready(pg_handle* h, bool need_fine) {
     return PG_OK;
 }
 
-int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
-                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
-                const float* points = nullptr, const float* pnoise = nullptr, bool guide_pass = false) {
+int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
+                    const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage,
+                    const float* points, const float* pnoise, bool guide_pass) {
     // PG_PREC_FP16M: the coarse pass of a hierarchical render only places the importance samples (and fills
     // rgb0/acc0): plain fp16 there, compensated fp16 wherever the pass produces the returned maps
     const int prec = h->cfg.precision == PG_PREC_FP16M ? (guide_pass ? PG_PREC_FP16 : PG_PREC_FP16C) : h->cfg.precision;
@@ -342,6 +342,26 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
         h->prof_points += a.n_points;
     }
     if (e) return pg_fail(h, PG_EHIP, "fused embed+MLP kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return PG_OK;
+}
+
+// One net on n rays x S samples.  Calls with more than REC_BATCH_RAYS rays run as consecutive launches over ray
+// ranges (rays are independent): the per-ray records (8.75 / 16.75 KiB per ray) then need 4.6 / 9 GB at most instead
+// of growing with the call (a 2048 x 2048 frame would ask for 72 GB).  POSEGEN_REC_BATCH overrides the size (tests).
+int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const float* rays, const float* z,
+                const float* skts, long long pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage = 0,
+                const float* points = nullptr, const float* pnoise = nullptr, bool guide_pass = false) {
+    long long batch = 1ll << 19;
+    if (const char* e = std::getenv("POSEGEN_REC_BATCH")) { const long long v = std::atoll(e); if (v >= 64) batch = v; }
+    if (points || dbg || n <= batch)
+        return launch_eval_one(h, stream, which, n, S, rays, z, skts, pose_stride, cams, raw, dbg, dbg_stage, points, pnoise, guide_pass);
+    for (long long r0 = 0; r0 < n; r0 += batch) {
+        const long long m = std::min(batch, n - r0);
+        const int rc = launch_eval_one(h, stream, which, m, S, rays + r0 * 11, z + r0 * S, skts + r0 * pose_stride, pose_stride,
+                                       cams ? cams + r0 : nullptr, raw + r0 * S * 4, nullptr, 0, nullptr,
+                                       pnoise ? pnoise + r0 * S * 3 : nullptr, guide_pass);
+        if (rc) return rc;
+    }
     return PG_OK;
 }
 

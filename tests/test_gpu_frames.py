@@ -89,6 +89,27 @@ def test_rays_are_independent_of_batching(caster):
         assert torch.equal(full[k][5000:5777], part[k])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16c"])
+def test_large_calls_run_as_ray_range_launches_with_identical_results(caster, prec, monkeypatch):
+    """A call with more rays than the record batch (2^19 by default; POSEGEN_REC_BATCH here) runs the per-ray record
+    kernel + the fused kernel over consecutive ray ranges, so that the record buffer does not grow with the call:
+    bitwise the single-launch result (every hit ray is independent of its neighbours)."""
+    from bench import full_frame_rays
+    from posegen_amd import PREC_BY_NAME
+    rb, skts, cyl, *_ = full_frame_rays(128, 128, torch.device(DEV))
+    r = caster.renderer
+    r.set_precision(PREC_BY_NAME[prec])
+    try:
+        one = r.render_rays(rb, skts, cyl, n_samples=64, n_importance=16, want_alpha=False)
+        monkeypatch.setenv("POSEGEN_REC_BATCH", "1000")             # 16384 rays -> 17 launches per pass, the last one short
+        many = r.render_rays(rb, skts, cyl, n_samples=64, n_importance=16, want_alpha=False)
+    finally:
+        monkeypatch.delenv("POSEGEN_REC_BATCH", raising=False)
+        r.set_precision(PREC_FP32)
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0"):
+        assert torch.equal(one[k], many[k]), k
+
+
 def test_render_full_image_from_a_camera_equals_explicit_rays(caster):
     """render(H, W, focal, c2w=...) without rays: the reference's full-image special case
     (trainer.py:109-113) = get_rays of every pixel, result reshaped to [H, W, ...]."""
