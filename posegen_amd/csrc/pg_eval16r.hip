@@ -22,6 +22,9 @@
 #ifndef PG_PREFETCH
 #define PG_PREFETCH 1
 #endif
+#ifndef PG_PIPE_H
+#define PG_PIPE_H 4           // A-pipe register sets in the hidden layers and heads: reads three units ahead (-0.3 % against two; five: the same)
+#endif
 #include "pg_eval16_common.h"
 
 // cache policy of the per-ray record fetches (streamed once; must not evict the weight stream from L2)
