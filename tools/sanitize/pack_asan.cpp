@@ -1,6 +1,6 @@
 // AddressSanitizer / UBSan run of the host packer (pg_pack.cpp) -- the only host-side native code with
 // non-trivial index arithmetic -- on the CPU (GPU sanitizers are not available on the pool).
-//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I posegen_amd/csrc \
+//   /opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I posegen_amd/csrc -I include \
 //       tools/sanitize/pack_asan.cpp posegen_amd/csrc/pg_pack.cpp -o /tmp/pack_asan && /tmp/pack_asan
 #include <cstdio>
 #include <random>
@@ -44,6 +44,13 @@ int main() {
             pack_bias_s(t, b);
             if (pack_vy(t, prec, fc != 0, vy) != 0) ++fails;
             std::printf("fc=%d prec=%d: small-tile stream %zu bytes, vy %zu bytes\n", fc, prec, s.size(), vy.size());
+        }
+        {   // record variant of the compensated-fp16 kernel: stream without the view-direction segment + fp32 Y-stage weights
+            std::vector<uint8_t> s;
+            std::vector<float> vyc;
+            if (pack_stream(t, PG_PREC_FP16C, fc != 0, true, s, nullptr, true) != 0) ++fails;
+            pack_vyc(t, fc != 0, vyc);
+            std::printf("fc=%d fp16c record variant: stream %zu bytes, vyc %zu floats\n", fc, s.size(), vyc.size());
         }
         std::vector<float> bias;
         pack_bias(t, bias);
