@@ -611,6 +611,11 @@ typedef float cal_f16v __attribute__((ext_vector_type(16)));
 // two 16-point column tiles of a wave's 32 points).  MI355X_MICROARCH.md (DVFS give-back 7): the chip can hold a
 // higher clock on one MFMA shape than on the other at equal cycles per FLOP, so the shapes are ranked by wall time.
 typedef float cal_f4v __attribute__((ext_vector_type(4)));
+// independent accumulators the loop cycles through, minus one (measurement aid: -DPG_CAL_MASK=1 is the two-accumulator
+// chain of a fused kernel's out-tile-major hidden layer: each MFMA accumulates onto the result of the one before the last)
+#ifndef PG_CAL_MASK
+#define PG_CAL_MASK 7
+#endif
 template <bool F16, bool LDSFED>
 __global__ __launch_bounds__(512) void mfma_rate_small_kernel(int iters, float* __restrict__ sink) {
     __shared__ __attribute__((aligned(16))) unsigned frag[32 * 256];
@@ -656,8 +661,8 @@ __global__ __launch_bounds__(512) void mfma_rate_small_kernel(int iters, float* 
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
                 const cal_u4 x = img[u * 64];
-                mma(acc[(2 * u) & 7], x, b0);
-                mma(acc[(2 * u + 1) & 7], x, b1);
+                mma(acc[(2 * u) & PG_CAL_MASK], x, b0);
+                mma(acc[(2 * u + 1) & PG_CAL_MASK], x, b1);
             }
         }
     } else {
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(512) void mfma_rate_small_kernel(int iters, float* 
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { mma(acc[2 * c], a, b0); mma(acc[2 * c + 1], a, b1); }
+                for (int c = 0; c < 4; ++c) { mma(acc[(2 * c) & PG_CAL_MASK], a, b0); mma(acc[(2 * c + 1) & PG_CAL_MASK], a, b1); }
         }
     }
     float r = 0.0f;
