@@ -187,3 +187,39 @@ def test_seeded_parity_sweep():
                      "fp16": 5e-3 if well else 2e-2, "bf16": 1e-2 if well else 3e-2}[m]
             assert worst <= bound, (rec["case"], rec["S"], rec["N"], m, worst)
             assert e["mse"] <= 1e-4, (rec["case"], m, e["mse"])
+
+
+@pytest.mark.parametrize("prec,bound", [("bf16", 2e-2), ("fp16", 1e-2), ("fp16c", 1e-3)])
+def test_record_kernels_on_odd_ray_and_sample_counts(prec, bound):
+    """The per-ray-record kernels (16x16x32 for bf16 / fp16, the record variant of the compensated kernel) against the fp32
+    kernel (direct view layer, no records) on shapes that stress their pass bookkeeping: ray counts that leave the last
+    pass and the last record tile ragged (1 ray ... 4097 rays), sample counts that make passes straddle 2 to 5 rays at
+    every offset (64 ... 200 samples), with and without importance samples.  fp32 is pinned to the reference by
+    test_gpu_parity.py; the bounds are what the modes' operand precision gives on random-weight nets with importance sampling
+    (tools/parity_sweep.py: worst cases 1.5e-2 / 1.2e-2 / 1.6e-4; one ray of the 2049 x (80 + 16) case here sits at 4.0e-4 in
+    fp16c, with records and, identically, in the direct form: its importance samples amplify a 1e-5 coarse difference) -- a
+    bookkeeping error shows as 0.1 ... 1."""
+    from bench import full_frame_rays
+    from posegen_amd import PREC_BY_NAME, surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRayCaster
+    cfg = surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 2), device=DEV, precision="fp32")
+    r = c.renderer
+    rb, skts, cyl, *_ = full_frame_rays(128, 128, torch.device(DEV))
+    rb = rb[torch.randperm(rb.shape[0], generator=torch.Generator().manual_seed(3)).to(DEV)]      # rays of a pass unrelated
+    worst = 0.0
+    try:
+        for n, S, N in ((1, 64, 0), (7, 65, 5), (33, 79, 16), (255, 96, 0), (1000, 127, 16), (4097, 64, 16), (513, 200, 8), (2049, 80, 16)):
+            x = rb[:n].contiguous()
+            r.set_precision(PREC_BY_NAME["fp32"])
+            ref = r.render_rays(x, skts, cyl, n_samples=S, n_importance=N, want_alpha=False)
+            r.set_precision(PREC_BY_NAME[prec])
+            got = r.render_rays(x, skts, cyl, n_samples=S, n_importance=N, want_alpha=False)
+            for k in ("rgb_map", "acc_map"):
+                assert torch.isfinite(got[k]).all(), (n, S, N, k)
+                err = float((got[k] - ref[k]).abs().max())
+                worst = max(worst, err)
+                assert err <= bound, (prec, n, S, N, k, err)
+    finally:
+        r.close()
+    print(f"{prec}: worst |error| vs the fp32 kernel over the odd shapes {worst:.2e}")
