@@ -223,3 +223,33 @@ def test_record_kernels_on_odd_ray_and_sample_counts(prec, bound):
     finally:
         r.close()
     print(f"{prec}: worst |error| vs the fp32 kernel over the odd shapes {worst:.2e}")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16c", "fp32"])
+def test_per_ray_poses_equal_the_per_pose_calls(prec):
+    """Per-ray skeleton transforms (skts [n,24,4,4], the layout the reference expands them to before the call,
+    raycasters.py:361-380): rays of two poses in ONE call, interleaved in blocks of 100, give bitwise what each pose's
+    own call gives -- the per-ray record kernels and the direct kernels read the pose of the ray, not of the call."""
+    from bench import full_frame_rays
+    from posegen_amd import PREC_BY_NAME, surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRayCaster
+    cfg = surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 1), device=DEV, precision=prec)
+    r = c.renderer
+    rb, skts_a, cyl, *_ = full_frame_rays(128, 128, torch.device(DEV))
+    _, _, skts_np = syn.make_pose(2, 5)
+    skts_b = torch.tensor(skts_np[1:2], device=DEV)
+    n = 3000
+    x = rb[4000:4000 + n].contiguous()
+    which = (torch.arange(n, device=DEV) // 100) % 2 == 1
+    per_ray = torch.where(which[:, None, None, None], skts_b.expand(n, -1, -1, -1), skts_a.expand(n, -1, -1, -1)).contiguous()
+    try:
+        both = r.render_rays(x, per_ray, cyl, n_samples=64, n_importance=16, want_alpha=False)
+        one_a = r.render_rays(x, skts_a, cyl, n_samples=64, n_importance=16, want_alpha=False)
+        one_b = r.render_rays(x, skts_b, cyl, n_samples=64, n_importance=16, want_alpha=False)
+    finally:
+        r.close()
+    for k in ("rgb_map", "acc_map", "disp_map"):
+        w = which if both[k].dim() == 1 else which[:, None]
+        assert torch.equal(both[k], torch.where(w, one_b[k], one_a[k])), k
+    assert float((one_a["rgb_map"] - one_b["rgb_map"]).abs().max()) > 1e-3        # the poses do differ
