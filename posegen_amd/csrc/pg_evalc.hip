@@ -24,6 +24,10 @@
 // with one wave per SIMD nothing else would overlap that VALU work with the matrix pipe.
 // The weight stream is staged L2 -> LDS by LDS-DMA into the 3 x 32 KiB ring of pg_device.h and read
 // by hand-issued ds_read_b128 four units ahead with counted lgkmcnt waits (pg_eval16_common.h).
+// Two forms of the view layer's direction part (template parameter REC of evalc_kernel): the direct one (per-ray
+// sin/cos table in LDS x per-point cutoff weight, 32 <= samples per ray < 64) and, for rays with >= 64 samples, the
+// record variant: per-ray (a, b) and split Y records of pg_rayrec.hip fetched by LDS-DMA, a second stage of 16-32 MFMAs
+// on the point's cutoff weights instead of 336, no table build, no divisions.
 #include <type_traits>
 
 #include "pg_eval16_common.h"

@@ -1,4 +1,5 @@
-// pg_rayrec.hip -- per-ray records of the factorised 16-bit path (pg_layout.h "per-ray records").
+// pg_rayrec.hip -- per-ray records of the factorised view layer: ray_records_kernel for the 16-bit path (pg_eval16r.hip),
+// ray_records_c_kernel for the compensated-fp16 path (pg_evalc.hip, record variant) -- pg_layout.h "per-ray records".
 //
 // The 648-wide view-direction input of a point is w_j(point) * T[ray][j][k] (core/encoders.py:25-37, 172-193;
 // core/cutoff_embedder.py:111-174 with dist_inputs=True): 27 values per joint that depend on the RAY only, times
