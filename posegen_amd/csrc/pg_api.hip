@@ -30,7 +30,8 @@ int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int rec, int grid, vo
 int pg_launch_ray_records_c(const pgd::RecArgs* a, int framecode, int n_cu, void* stream);
 int pg_evalc_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
-                            int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
+                            int S, int lindisp, float* near_far, float* z, const float* t_rand, double* scratch, void* stream);
+long long pg_sample_coarse_scratch(long long n, int chunk);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
 int pg_launch_mfma_rate(int f16, int lds_fed, int blocks, int iters, float* sink, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
@@ -367,6 +368,22 @@ int launch_eval(pg_handle* h, void* stream, int which, long long n, int S, const
 
 }  // namespace
 
+int pg_sc_scratch(pg_handle* h, long long n, int chunk, double** out) {
+    *out = nullptr;
+    const long long need = pg_sample_coarse_scratch(n, chunk);
+    if (need <= 0) return PG_OK;
+    if ((size_t)need > h->sc_part_cap) {
+        PG_HIP(h, hipSetDevice(h->device));
+        if (h->sc_part) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(h->sc_part)); h->sc_part = nullptr; h->sc_part_cap = 0; }
+        const size_t want = (size_t)need * 2;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->sc_part), want * sizeof(double));
+        if (e != hipSuccess) return pg_fail(h, PG_ENOMEM, "coarse sampler scratch of %zu doubles failed: %s", want, hipGetErrorString(e));
+        h->sc_part_cap = want;
+    }
+    *out = h->sc_part;
+    return PG_OK;
+}
+
 extern "C" {
 
 int pg_abi_version(void) { return PG_ABI_VERSION; }
@@ -462,6 +479,7 @@ void pg_destroy(pg_handle* h) {
     if (h->d_pose) (void)hipFree(h->d_pose);
     if (h->fws) (void)hipFree(h->fws);
     if (h->rec) (void)hipFree(h->rec);
+    if (h->sc_part) (void)hipFree(h->sc_part);
     pg_train_release(h);
     for (auto& pr : h->ev_aux) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (NetState& ns : h->net) {
@@ -764,8 +782,10 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
     if (n_samples < 2) return pg_fail(h, PG_EINVAL, "pg_stage_sample_coarse: N_samples must be >= 2");
     if (cyl_stride != 0 && cyl_stride != 5) return pg_fail(h, PG_EINVAL, "cyl_stride must be 0 or 5");
     PG_HIP(h, hipSetDevice(h->device));
+    double* scs = nullptr;
+    if (int rc = pg_sc_scratch(h, n, h->cfg.chunk, &scs)) return rc;
     int e = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, n_samples,
-                                    (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, nullptr, stream);
+                                    (flags & PG_FLAG_LINDISP) ? 1 : 0, near_far, z, nullptr, scs, stream);
     if (e) return pg_fail(h, PG_EHIP, "sample_coarse launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
 }
@@ -876,8 +896,10 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
 
     // near/far + coarse depths; with perturb the stratified jitter from the caller's draws (ray_utils.py:229-246)
     {
+        double* scs = nullptr;
+        if (int rc = pg_sc_scratch(h, n, h->cfg.chunk, &scs)) return rc;
         int e0 = pg_launch_sample_coarse(ray_batch, cyls, cyl_stride, n, h->cfg.chunk, S, (flags & PG_FLAG_LINDISP) ? 1 : 0, nf, zc,
-                                         dr ? dr->t_rand : nullptr, stream);
+                                         dr ? dr->t_rand : nullptr, scs, stream);
         if (e0) return pg_fail(h, PG_EHIP, "coarse sampling launch failed: %s", hipGetErrorString((hipError_t)e0));
     }
     if (rnoise) {       // position noise of the coarse points: rows [:S] of every ray's draws

@@ -41,6 +41,8 @@ struct pg_handle {
     size_t ws_bytes = 0;
     uint8_t* fws = nullptr;          // frame front/back end: ray_batch, cams, rgb/disp/acc maps of the box
     size_t fws_bytes = 0;
+    double* sc_part = nullptr;       // partial nanmean sums of the two-launch coarse sampler (pg_kernels.hip)
+    size_t sc_part_cap = 0;          // ... doubles
     uint8_t* rec = nullptr;          // per-ray records of the factorised 16-bit path: Y [n + pad, 8 KiB] then (a, b) [n + pad, 768 B]
     size_t rec_bytes = 0;
     // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
@@ -57,6 +59,8 @@ struct pg_handle {
 };
 
 extern "C" void pg_train_release(pg_handle* h);
+// scratch of pg_launch_sample_coarse for n rays in chunks of `chunk` (null when the one-launch form runs)
+int pg_sc_scratch(pg_handle* h, long long n, int chunk, double** out);
 
 // records the message (handle and thread-local "last error") and returns `code`
 int pg_fail(pg_handle* h, int code, const char* fmt, ...);

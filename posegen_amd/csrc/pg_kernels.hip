@@ -134,6 +134,116 @@ __global__ __launch_bounds__(SC_THREADS) void sample_coarse_kernel(
     }
 }
 
+// The same in two launches for chunks of more than SC_SUB rays (a training batch is ONE chunk of N_rand rays, a direct
+// forward call one chunk of the whole batch: a single workgroup per chunk then crawls): blocks of SC_SUB rays write
+// their near/far and partial nanmean sums (sc_partial_kernel), then every block adds its chunk's partials in index
+// order -- fp64, so the mean is the one the single-block form computes except for the order of a few double additions --
+// and emits the depths with a wave per ray (coalesced rows of z).
+constexpr int SC_SUB = 256;
+
+__global__ __launch_bounds__(SC_THREADS) void sc_partial_kernel(
+        const float* __restrict__ rays, const float* __restrict__ cyls, long long cyl_stride,
+        long long n, int chunk, int nsub, float* __restrict__ near_far, double* __restrict__ part) {
+    __shared__ double red[SC_THREADS / 64][4];
+    __shared__ int any_nan;
+    const long long group = blockIdx.x / nsub, sub = blockIdx.x % nsub;
+    const long long c0 = group * chunk + sub * SC_SUB;
+    const long long c1 = min(min(c0 + SC_SUB, (group + 1) * chunk), n);
+    const int tid = threadIdx.x;
+    if (tid == 0) any_nan = 0;
+    __syncthreads();
+    double v[4] = {0.0, 0.0, 0.0, 0.0};         // sum near, count near, sum far, count far
+    bool saw_nan = false;
+    for (long long r = c0 + tid; r < c1; r += SC_THREADS) {
+        float nn, ff;
+        bool qn;
+        ray_near_far(rays + r * 11, cyls + r * cyl_stride, nn, ff, qn);
+        near_far[r * 2 + 0] = nn;
+        near_far[r * 2 + 1] = ff;
+        if (!isnan(nn)) { v[0] += nn; v[1] += 1.0; } else saw_nan = true;
+        if (!isnan(ff)) { v[2] += ff; v[3] += 1.0; }
+    }
+    if (saw_nan) any_nan = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { red[wave][0] = v[0]; red[wave][1] = v[1]; red[wave][2] = v[2]; red[wave][3] = v[3]; }
+    __syncthreads();
+    if (tid == 0) {
+        double o[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < SC_THREADS / 64; ++w)
+            for (int k = 0; k < 4; ++k) o[k] += red[w][k];
+        double* dst = part + (long long)blockIdx.x * 5;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; dst[4] = any_nan ? 1.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(SC_THREADS) void sc_sample_kernel(
+        const float* __restrict__ rays, const float* __restrict__ cyls, long long cyl_stride,
+        long long n, int chunk, int nsub, int S, int lindisp,
+        float* __restrict__ near_far, float* __restrict__ z, const float* __restrict__ t_rand, const double* __restrict__ part) {
+    __shared__ float fix[2];
+    __shared__ int any_nan;
+    const long long group = blockIdx.x / nsub, sub = blockIdx.x % nsub;
+    const long long c0 = group * chunk + sub * SC_SUB;
+    const long long c1 = min(min(c0 + SC_SUB, (group + 1) * chunk), n);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        double sn = 0, cn = 0, sf = 0, cf = 0, an = 0;
+        for (int k = 0; k < nsub; ++k) {
+            const double* p = part + (group * nsub + k) * 5;
+            sn += p[0]; cn += p[1]; sf += p[2]; cf += p[3]; an += p[4];
+        }
+        fix[0] = cn > 0 ? (float)(sn / cn) : __builtin_nanf("");
+        fix[1] = cf > 0 ? (float)(sf / cf) : __builtin_nanf("");
+        any_nan = an > 0.0;
+    }
+    __syncthreads();
+    const bool patch = any_nan != 0;
+    const float m_near = fix[0], m_far = fix[1];
+    const float step = 1.0f / (float)(S - 1);
+    // a wave takes 64 rays at a time: lane k computes ray k's near/far (and patch), then the wave writes the 64 rows of
+    // depths one after the other, a lane per depth (coalesced 4 S-byte rows)
+    for (long long base = c0 + wave * 64; base < c1; base += SC_THREADS) {
+        const long long rl = base + lane;
+        float nn = 1.0f, ff = 2.0f;
+        if (rl < c1) {
+            bool qn;
+            ray_near_far(rays + rl * 11, cyls + rl * cyl_stride, nn, ff, qn);
+            if (patch && qn) {
+                nn = isnan(m_near) ? rays[rl * 11 + 6] : m_near;
+                ff = isnan(m_far) ? rays[rl * 11 + 7] : m_far;
+                near_far[rl * 2 + 0] = nn;
+                near_far[rl * 2 + 1] = ff;
+            }
+        }
+        const int cnt = (int)min((long long)64, c1 - base);
+        for (int k = 0; k < cnt; ++k) {
+            const long long r = base + k;
+            const float nk = __shfl(nn, k), fk = __shfl(ff, k);
+            auto depth = [&](int s) {
+                const float t = s < S / 2 ? __fmul_rn(step, (float)s) : __fsub_rn(1.0f, __fmul_rn(step, (float)(S - 1 - s)));
+                if (!lindisp) return __fadd_rn(__fmul_rn(nk, __fsub_rn(1.0f, t)), __fmul_rn(fk, t));
+                const float a = __fmul_rn(__fdiv_rn(1.0f, nk), __fsub_rn(1.0f, t));
+                const float b = __fmul_rn(__fdiv_rn(1.0f, fk), t);
+                return __fdiv_rn(1.0f, __fadd_rn(a, b));
+            };
+            for (int s = lane; s < S; s += 64) {
+                float zv = depth(s);
+                if (t_rand) {   // stratified jitter (ray_utils.py:229-246): between the midpoints to the neighbours
+                    const float cur = zv, prev = s > 0 ? depth(s - 1) : cur, nxt = s + 1 < S ? depth(s + 1) : cur;
+                    const float lower = s == 0 ? cur : __fmul_rn(0.5f, __fadd_rn(cur, prev));
+                    const float upper = s + 1 < S ? __fmul_rn(0.5f, __fadd_rn(nxt, cur)) : cur;
+                    zv = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[r * S + s]));
+                }
+                z[r * S + s] = zv;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // raw2outputs (reference core/networks/nerf.py:150-205, eval: no noise) and, when
 // n_imp > 0, isample_from_lineseg / sample_pdf with det=True
@@ -568,10 +678,27 @@ extern "C" int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb
     return (int)hipGetLastError();
 }
 
+// doubles of scratch the two-launch form needs for n rays in chunks of `chunk` (0: the one-launch form is used)
+extern "C" long long pg_sample_coarse_scratch(long long n, int chunk) {
+    if (n <= 0 || chunk <= pgk::SC_SUB) return 0;
+    const long long groups = (n + chunk - 1) / chunk, nsub = (chunk + pgk::SC_SUB - 1) / pgk::SC_SUB;
+    return groups * nsub * 5;
+}
+
 extern "C" int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride,
                                        long long n, int chunk, int S, int lindisp,
-                                       float* near_far, float* z, const float* t_rand, void* stream) {
+                                       float* near_far, float* z, const float* t_rand, double* scratch, void* stream) {
     if (n <= 0) return 0;
+    if (scratch && chunk > pgk::SC_SUB) {
+        const long long groups = (n + chunk - 1) / chunk;
+        const int nsub = (chunk + pgk::SC_SUB - 1) / pgk::SC_SUB;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        hipLaunchKernelGGL(pgk::sc_partial_kernel, dim3((unsigned)(groups * nsub)), dim3(pgk::SC_THREADS), 0, s,
+                           rays, cyls, cyl_stride, n, chunk, nsub, near_far, scratch);
+        hipLaunchKernelGGL(pgk::sc_sample_kernel, dim3((unsigned)(groups * nsub)), dim3(pgk::SC_THREADS), 0, s,
+                           rays, cyls, cyl_stride, n, chunk, nsub, S, lindisp, near_far, z, t_rand, scratch);
+        return (int)hipGetLastError();
+    }
     const long long blocks = (n + chunk - 1) / chunk;
     hipLaunchKernelGGL(pgk::sample_coarse_kernel, dim3((unsigned)blocks), dim3(pgk::SC_THREADS), 0,
                        static_cast<hipStream_t>(stream), rays, cyls, cyl_stride, n, chunk, S, lindisp,

@@ -25,7 +25,7 @@
 
 extern "C" {
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
-                            int S, int lindisp, float* near_far, float* z, const float* t_rand, void* stream);
+                            int S, int lindisp, float* near_far, float* z, const float* t_rand, double* scratch, void* stream);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
                         float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
@@ -649,7 +649,9 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     const float* codes_dev[2] = {coarse->codes, N > 0 ? fine->codes : nullptr};
 
     Pass& pc = t.pass[0];
-    int e = pg_launch_sample_coarse(t.rays, cyls, cyl_stride, n, h->cfg.chunk, S, (flags & PG_FLAG_LINDISP) ? 1 : 0, nf, pc.z, dr ? dr->t_rand : nullptr, stream);
+    double* scs = nullptr;
+    { const int rc_ = pg_sc_scratch(h, n, h->cfg.chunk, &scs); if (rc_) return rc_; }
+    int e = pg_launch_sample_coarse(t.rays, cyls, cyl_stride, n, h->cfg.chunk, S, (flags & PG_FLAG_LINDISP) ? 1 : 0, nf, pc.z, dr ? dr->t_rand : nullptr, scs, stream);
     if (e) return pg_fail(h, PG_EHIP, "coarse sampling launch failed: %s", hipGetErrorString((hipError_t)e));
     if (dr && dr->noise0) PG_HIP(h, hipMemcpyAsync(pc.noise, dr->noise0, (size_t)Pc * 4, hipMemcpyDeviceToDevice, s));
     if (rnoise) {
