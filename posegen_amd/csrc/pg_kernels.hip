@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace pgk {
 
@@ -290,19 +291,16 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-__global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
+// one ray by one wave (sh_*: the wave's rows of the workgroup's LDS arrays)
+__device__ __forceinline__ void composite_ray(
+        const long long ray, const int lane, const int wave,
+        float (*sh_w)[CP_MAXS], float (*sh_z)[CP_MAXS + CP_MAXI], float (*sh_cdf)[CP_MAXS],
         const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ raw,
-        long long n, int S, float density_scale, float rgb_eps,
+        int S, float density_scale, float rgb_eps,
         float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
         float* __restrict__ alpha_out, float* __restrict__ w_out,
         int n_imp, float* __restrict__ z_fine, const float* __restrict__ noise, const float* __restrict__ u_rand,
         int* __restrict__ order) {
-    __shared__ float sh_w[CP_WAVES][CP_MAXS];
-    __shared__ float sh_z[CP_WAVES][CP_MAXS + CP_MAXI];
-    __shared__ float sh_cdf[CP_WAVES][CP_MAXS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long ray = (long long)blockIdx.x * CP_WAVES + wave;
-    if (ray >= n) return;                       // wave-uniform; no block barriers below
     const int E = (S + 63) >> 6;
     const float* rb = rays + ray * 11;
     const float dnorm = sqrtf(rb[3] * rb[3] + rb[4] * rb[4] + rb[5] * rb[5]);
@@ -444,6 +442,26 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
         }
         z_fine[ray * NTOT + rank] = x;
         if (order) order[ray * NTOT + rank] = i;       // sorted_idxs of torch.sort(cat([z, z_samples]))
+    }
+}
+
+// A wave takes rays blockIdx.x * CP_WAVES + wave, + gridDim.x * CP_WAVES, ...: a few rays per wave instead of one
+// (262 144 one-ray waves per 512 x 512 launch are bound by the rate waves can be dispatched, not by their 2 KB of traffic).
+__global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
+        const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ raw,
+        long long n, int S, float density_scale, float rgb_eps,
+        float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
+        float* __restrict__ alpha_out, float* __restrict__ w_out,
+        int n_imp, float* __restrict__ z_fine, const float* __restrict__ noise, const float* __restrict__ u_rand,
+        int* __restrict__ order) {
+    __shared__ float sh_w[CP_WAVES][CP_MAXS];
+    __shared__ float sh_z[CP_WAVES][CP_MAXS + CP_MAXI];
+    __shared__ float sh_cdf[CP_WAVES][CP_MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long ray = (long long)blockIdx.x * CP_WAVES + wave; ray < n; ray += (long long)gridDim.x * CP_WAVES) {
+        composite_ray(ray, lane, wave, sh_w, sh_z, sh_cdf, rays, z, raw, S, density_scale, rgb_eps, rgb_out, disp_out, acc_out,
+                      alpha_out, w_out, n_imp, z_fine, noise, u_rand, order);
+        PG_WAVE_SYNC();                         // the wave's LDS rows are reused by its next ray
     }
 }
 
@@ -711,7 +729,8 @@ extern "C" int pg_launch_composite(const float* rays, const float* z, const floa
                                    float* alpha, float* weights, int n_imp, float* z_fine, const float* noise,
                                    const float* u_rand, int* order, void* stream) {
     if (n <= 0) return 0;
-    const long long blocks = (n + pgk::CP_WAVES - 1) / pgk::CP_WAVES;
+    long long blocks = (n + pgk::CP_WAVES - 1) / pgk::CP_WAVES;
+    if (blocks > 16384) blocks = 16384;         // a wave takes several rays (measured flat from 4 k to 32 k blocks, -0.05 ms per frame against one ray per wave)
     hipLaunchKernelGGL(pgk::composite_kernel, dim3((unsigned)blocks), dim3(pgk::CP_WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), rays, z, reinterpret_cast<const float4*>(raw), n, S,
                        density_scale, rgb_eps, rgb, disp, acc, alpha, weights, n_imp, z_fine, noise, u_rand, order);
