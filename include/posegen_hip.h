@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 6
+#define PG_ABI_VERSION 7
 
 /* error codes */
 #define PG_OK 0
@@ -56,6 +56,10 @@ extern "C" {
                              * rgb0/disp0/acc0/alpha0 are plain fp16's. */
 #define PG_PREC_MODES 7
 
+/* density activation of raw2outputs (get_density_fn, core/raycasters.py:230-238) */
+#define PG_ACT_RELU 0       /* F.relu                                                  */
+#define PG_ACT_SOFTPLUS 1   /* F.softplus(x - softplus_shift, beta=1) (threshold 20)   */
+
 /* flags of pg_render_rays */
 #define PG_FLAG_LINDISP 1   /* sample linearly in inverse depth (ray_utils.py:224-227) */
 
@@ -80,7 +84,10 @@ typedef struct pg_config {
     float cutoff_dist;       /* cutoff_mm * ext_scale   (raycasters.py:33)            */
     float density_scale;     /* --density_scale (B of raw2outputs)                    */
     float rgb_eps;           /* 1e-3                     nerf.py:151                  */
-    float reserved0;
+    float softplus_shift;    /* --softplus_shift (used when density_act == PG_ACT_SOFTPLUS)       */
+    int32_t density_act;     /* --density_type: PG_ACT_RELU | PG_ACT_SOFTPLUS (get_density_fn,
+                              * core/raycasters.py:230-238: the act_fn of raw2outputs, nerf.py:164) */
+    int32_t reserved0;
 } pg_config;
 
 /* Device output pointers of one pg_render_rays call; any may be NULL (not wanted).
@@ -222,17 +229,21 @@ typedef struct pg_net_grads {
 
 /* Forward of RayCaster.render_rays in training mode (core/raycasters.py:361-474; draws as in pg_render_rays_train,
  * may be NULL) with every activation kept on a tape inside the handle: arguments as pg_render_rays; `fine` may be
- * NULL when n_importance == 0.  The parameter tensors and the tape stay in use until pg_train_backward. */
+ * NULL when n_importance == 0.  The parameter tensors and the tape stay in use until pg_train_backward.  The handle
+ * holds ONE tape: *tape_id (may be NULL) receives the id of this pass, which pg_train_backward must present -- a
+ * forward pass in between overwrites the tape and makes the older id stale (PG_ESTATE) instead of silently
+ * differentiating the wrong activations. */
 int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts, int64_t pose_stride,
                      const float* cyls, int64_t cyl_stride, const float* cams, int n_samples, int n_importance, int flags,
-                     const pg_train_draws* draws, const pg_net_params* coarse, const pg_net_params* fine, const pg_outputs* out);
+                     const pg_train_draws* draws, const pg_net_params* coarse, const pg_net_params* fine, const pg_outputs* out,
+                     int64_t* tape_id);
 
-/* Backward of the last pg_train_forward: given dL/d(rgb_map) [n,3], dL/d(acc_map) [n], dL/d(rgb0) [n,3], dL/d(acc0) [n]
+/* Backward of the pg_train_forward that returned `tape_id` (it must still be the last one): given dL/d(rgb_map) [n,3], dL/d(acc_map) [n], dL/d(rgb0) [n,3], dL/d(acc0) [n]
  * (device, any may be NULL = zero; what Trainer.compute_loss reads, core/trainer.py:321-383), the gradient of L with
  * respect to every parameter tensor of both nets.  The importance samples are constants (`z_samples.detach()`,
  * core/utils/ray_utils.py:285). */
-int pg_train_backward(pg_handle* h, void* stream, const float* d_rgb_map, const float* d_acc_map, const float* d_rgb0,
-                      const float* d_acc0, const pg_net_grads* coarse, const pg_net_grads* fine);
+int pg_train_backward(pg_handle* h, void* stream, int64_t tape_id, const float* d_rgb_map, const float* d_acc_map,
+                      const float* d_rgb0, const float* d_acc0, const pg_net_grads* coarse, const pg_net_grads* fine);
 
 /* One frame with its front and back end on the device.  Replaces, per
  * frame: get_rays + the bounding-box gather of kp_to_valid_rays (core/utils/ray_utils.py:6-28,

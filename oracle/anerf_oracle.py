@@ -87,6 +87,8 @@ class OracleConfig:
     tau_d: float = 20.0          # CutoffEmbedder.tau of embeddirs_fn
     density_scale: float = 1.0
     rgb_eps: float = 1e-3
+    density_type: str = "relu"   # 'relu' | 'softplus' (get_density_fn, core/raycasters.py:230-238)
+    softplus_shift: float = 1.0
     # None = the reference's fp32.  'bf16' / 'fp16' / 'bf16x3' / 'fp16x3' / 'fp16c' EMULATE the MFMA
     # operand rounding of the HIP kernel's precision modes (operands rounded to the 16-bit
     # type, or split into hi+lo halves with the lo*lo term dropped; products exact, fp32
@@ -435,7 +437,9 @@ def composite(raw, z, rays_d, cfg: OracleConfig, noise=None):
     delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1)
     delta = delta * torch.norm(rays_d[:, None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3]) * (1 + 2 * cfg.rgb_eps) - cfg.rgb_eps
-    alpha = 1. - torch.exp(-F.relu(raw[..., 3] / cfg.density_scale + (0. if noise is None else noise)) * delta)
+    # act_fn of raw2outputs (nerf.py:164): F.relu or F.softplus(x - shift, beta=1) (raycasters.py:230-238)
+    act = F.relu if cfg.density_type == "relu" else (lambda x: F.softplus(x - cfg.softplus_shift, beta=1))
+    alpha = 1. - torch.exp(-act(raw[..., 3] / cfg.density_scale + (0. if noise is None else noise)) * delta)
     trans = torch.cumprod(torch.cat([torch.ones(z.shape[0], 1), 1. - alpha + 1e-10], -1), -1)[:, :-1]
     w = alpha * trans
     rgb_map = torch.sum(w[..., None] * rgb, -2)

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
-PG_ABI_VERSION = 6
+PG_ACT_RELU, PG_ACT_SOFTPLUS = 0, 1
+PG_ABI_VERSION = 7
 
 
 class HipLibraryError(RuntimeError):
@@ -36,7 +37,7 @@ class PgConfig(C.Structure):
                 ("skip_layer", C.c_int32), ("view_width", C.c_int32), ("framecode_ch", C.c_int32),
                 ("n_framecodes", C.c_int32), ("chunk", C.c_int32), ("precision", C.c_int32),
                 ("cutoff_dist", C.c_float), ("density_scale", C.c_float), ("rgb_eps", C.c_float),
-                ("reserved0", C.c_float)]
+                ("softplus_shift", C.c_float), ("density_act", C.c_int32), ("reserved0", C.c_int32)]
 
 
 _FP = C.c_void_p  # device float*
@@ -113,8 +114,9 @@ PROTOTYPES = {
     "pg_compose_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP, C.c_int, C.c_int, C.c_int,
-                                   C.POINTER(PgTrainDraws), C.POINTER(PgNetParams), C.POINTER(PgNetParams), C.POINTER(PgOutputs)]),
-    "pg_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, _FP, _FP, _FP, _FP, C.POINTER(PgNetGrads), C.POINTER(PgNetGrads)]),
+                                   C.POINTER(PgTrainDraws), C.POINTER(PgNetParams), C.POINTER(PgNetParams), C.POINTER(PgOutputs),
+                                   C.POINTER(C.c_int64)]),
+    "pg_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, _FP, _FP, C.POINTER(PgNetGrads), C.POINTER(PgNetGrads)]),
     "pg_plan_frames": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                  C.POINTER(C.c_int)]),
 }

@@ -44,6 +44,8 @@ class RenderConfig:
     chunk: int = 4096              # --chunk
     density_scale: float = 1.0     # --density_scale
     rgb_eps: float = 1e-3          # nerf.py:151
+    density_type: str = "relu"     # --density_type: 'relu' | 'softplus' (get_density_fn, raycasters.py:230-238)
+    softplus_shift: float = 1.0    # --softplus_shift: softplus(x - shift)
     lindisp: bool = False
     white_bkgd: bool = True
 

@@ -35,8 +35,8 @@ long long pg_sample_coarse_scratch(long long n, int chunk);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
 int pg_launch_mfma_rate(int f16, int lds_fed, int blocks, int iters, float* sink, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
-                        float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
-                        float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
+                        float density_scale, float rgb_eps, int density_act, float act_shift, float* rgb, float* disp, float* acc,
+                        float* alpha, float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
                         void* stream);
 int pg_composite_max_samples(void);
 int pg_composite_max_importance(void);
@@ -66,6 +66,8 @@ namespace {
 using namespace pgl;
 
 thread_local char g_last_error[512] = "";      // pg_last_error(NULL): per host thread
+
+void frames_cache_release(pg_handle* h);       // per-device buffers of pg_render_frames (defined beside it)
 
 }  // namespace
 
@@ -151,6 +153,7 @@ int ensure_rec(pg_handle* h, int64_t n, int y_bytes) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->rec), want);
     if (e != hipSuccess) return pg_fail(h, PG_ENOMEM, "ray record buffer of %zu bytes failed: %s", want, hipGetErrorString(e));
     h->rec_bytes = want;
+    h->rec_pad_n = -1;
     return PG_OK;
 }
 
@@ -286,10 +289,14 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
         a.rec_y = h->rec;
         a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes);
         // the padding rays behind the last record are fetched by the last passes (their values are multiplied by
-        // zero weights at most): keep them finite whatever the buffer held before
-        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * y_bytes, 0, (size_t)REC_PAD_RAYS * y_bytes, static_cast<hipStream_t>(stream)));
-        PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes + (size_t)n * REC_AB_BYTES, 0,
-                                 (size_t)REC_PAD_RAYS * REC_AB_BYTES, static_cast<hipStream_t>(stream)));
+        // zero weights at most): keep them finite whatever the buffer held before.  The record kernels write rays
+        // < n only, so the padding of an (n, record size) pair stays zero until another pair moves it.
+        if (h->rec_pad_n != n || h->rec_pad_y != y_bytes) {
+            PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * y_bytes, 0, (size_t)REC_PAD_RAYS * y_bytes, static_cast<hipStream_t>(stream)));
+            PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes + (size_t)n * REC_AB_BYTES, 0,
+                                     (size_t)REC_PAD_RAYS * REC_AB_BYTES, static_cast<hipStream_t>(stream)));
+            h->rec_pad_n = n; h->rec_pad_y = y_bytes;
+        }
     }
     a.cutoff = h->d_cut;
     a.raw = raw; a.dbg = dbg;
@@ -325,7 +332,11 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
         hipEvent_t x0 = nullptr, x1 = nullptr;
         if (h->profiling) { PG_HIP(h, get(x0)); PG_HIP(h, get(x1)); PG_HIP(h, hipEventRecord(x0, static_cast<hipStream_t>(stream))); }
         const int er = crec ? pg_launch_ray_records_c(&ra, fc, h->n_cu, stream) : pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);
-        if (h->profiling) { PG_HIP(h, hipEventRecord(x1, static_cast<hipStream_t>(stream))); h->ev_aux.emplace_back(x0, x1); }
+        if (h->profiling) {
+            PG_HIP(h, hipEventRecord(x1, static_cast<hipStream_t>(stream)));
+            if (er) { h->ev_free.push_back(x0); h->ev_free.push_back(x1); }      // a failed launch is not a sample
+            else h->ev_aux.emplace_back(x0, x1);
+        }
         if (er) return pg_fail(h, PG_EHIP, "ray record kernel launch failed: %s", hipGetErrorString((hipError_t)er));
     }
     if (h->profiling) {
@@ -406,6 +417,8 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
         return pg_fail(nullptr, PG_EINVAL, "pg_create: split-operand precision %d is experimental (set POSEGEN_EXPERIMENTAL_X3=1)", cfg->precision);
     if (cfg->chunk <= 0) return pg_fail(nullptr, PG_EINVAL, "pg_create: chunk must be positive");
     if (!(cfg->density_scale > 0.f)) return pg_fail(nullptr, PG_EINVAL, "pg_create: density_scale must be positive");
+    if (cfg->density_act != PG_ACT_RELU && cfg->density_act != PG_ACT_SOFTPLUS)
+        return pg_fail(nullptr, PG_EINVAL, "pg_create: density_act must be PG_ACT_RELU or PG_ACT_SOFTPLUS, got %d", cfg->density_act);
     pg_handle* h = new (std::nothrow) pg_handle();
     if (!h) return pg_fail(nullptr, PG_ENOMEM, "pg_create: out of host memory");
     h->cfg = *cfg;
@@ -481,6 +494,7 @@ void pg_destroy(pg_handle* h) {
     if (h->rec) (void)hipFree(h->rec);
     if (h->sc_part) (void)hipFree(h->sc_part);
     pg_train_release(h);
+    frames_cache_release(h);
     for (auto& pr : h->ev_aux) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (NetState& ns : h->net) {
         for (auto& p : ns.d_stream_r) if (p) (void)hipFree(p);
@@ -604,21 +618,30 @@ int pg_profile_enable(pg_handle* h, int on) {
     return PG_OK;
 }
 
-int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms) {
-    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_read_aux: null handle");
-    PG_HIP(h, hipSetDevice(h->device));
-    double ms = 0.0;
+// the record-kernel events recorded so far -> the handle's running totals; the events go back to the pool (called by
+// both reads, so that a caller that only ever reads the fused kernel's numbers does not pile events up)
+static int fold_aux(pg_handle* h) {
     for (auto& pr : h->ev_aux) {
         PG_HIP(h, hipEventSynchronize(pr.second));
         float t = 0.f;
         PG_HIP(h, hipEventElapsedTime(&t, pr.first, pr.second));
-        ms += t;
+        h->aux_ms += t;
+        h->aux_n += 1;
         h->ev_free.push_back(pr.first);
         h->ev_free.push_back(pr.second);
     }
-    if (n_launches) *n_launches = (int64_t)h->ev_aux.size();
-    if (total_ms) *total_ms = ms;
     h->ev_aux.clear();
+    return PG_OK;
+}
+
+int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms) {
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_read_aux: null handle");
+    PG_HIP(h, hipSetDevice(h->device));
+    if (const int rc = fold_aux(h)) return rc;
+    if (n_launches) *n_launches = h->aux_n;
+    if (total_ms) *total_ms = h->aux_ms;
+    h->aux_n = 0;
+    h->aux_ms = 0.0;
     return PG_OK;
 }
 
@@ -639,7 +662,7 @@ int pg_profile_read(pg_handle* h, int64_t* n_launches, double* total_ms, int64_t
     if (n_points) *n_points = h->prof_points;
     h->ev_used.clear();
     h->prof_points = 0;
-    return PG_OK;
+    return fold_aux(h);             // (kept for the next pg_profile_read_aux)
 }
 
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
@@ -831,7 +854,7 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples, con
         return pg_fail(h, PG_EINVAL, "pg_stage_composite: N_importance %d outside {0, 2..%d}", n_importance, pg_composite_max_importance());
     if (n_importance > 0 && n_samples < 3) return pg_fail(h, PG_EINVAL, "importance sampling needs N_samples >= 3");
     PG_HIP(h, hipSetDevice(h->device));
-    int e = pg_launch_composite(ray_batch, z, raw, n, n_samples, h->cfg.density_scale, h->cfg.rgb_eps, rgb, disp, acc,
+    int e = pg_launch_composite(ray_batch, z, raw, n, n_samples, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, rgb, disp, acc,
                                 alpha, weights, n_importance, z_fine, nullptr, nullptr, nullptr, stream);
     if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     return PG_OK;
@@ -908,7 +931,7 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     }
     rc = launch_eval(h, stream, 0, n, S, ray_batch, zc, skts, pose_stride, cams, rawc, nullptr, 0, nullptr, rnoise ? pn : nullptr, hier);
     if (rc) return rc;
-    int e = pg_launch_composite(ray_batch, zc, rawc, n, S, h->cfg.density_scale, h->cfg.rgb_eps,
+    int e = pg_launch_composite(ray_batch, zc, rawc, n, S, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift,
                                 hier ? out->rgb0 : out->rgb_map, hier ? out->disp0 : out->disp_map,
                                 hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
                                 out->weights0 ? out->weights0 : w0, n_importance, hier ? zf : nullptr,
@@ -921,7 +944,7 @@ int render_rays_impl(pg_handle* h, void* stream, int64_t n, const float* ray_bat
         }
         rc = launch_eval(h, stream, 1, n, SF, ray_batch, zf, skts, pose_stride, cams, rawf, nullptr, 0, nullptr, rnoise ? pn : nullptr);
         if (rc) return rc;
-        e = pg_launch_composite(ray_batch, zf, rawf, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, out->rgb_map,
+        e = pg_launch_composite(ray_batch, zf, rawf, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, out->rgb_map,
                                 out->disp_map, out->acc_map, out->alpha, nullptr, 0, nullptr, dr ? dr->noise1 : nullptr,
                                 nullptr, nullptr, stream);
         if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -1167,6 +1190,156 @@ int pg_plan_frames(int n_frames, const int64_t* n_rays, int n_workers, int chunk
     return PG_OK;
 }
 
+// ---- pg_render_frames: per-device resources kept on the handle between calls -----------------------------------
+}  // extern "C"
+
+namespace {
+
+constexpr int NBUF = pg_handle::FramesCache::NBUF;
+
+void frames_cache_release(pg_handle* h) {
+    auto& c = h->fc;
+    (void)hipSetDevice(h->device);
+    for (int b = 0; b < NBUF; ++b) {
+        if (c.d_frame[b]) (void)hipFree(c.d_frame[b]);
+        if (c.copied[b]) (void)hipEventDestroy(c.copied[b]);
+        if (c.composed[b]) (void)hipEventDestroy(c.composed[b]);
+        c.d_frame[b] = nullptr; c.copied[b] = nullptr; c.composed[b] = nullptr;
+    }
+    if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream);
+    if (c.d_bg) (void)hipFree(c.d_bg);
+    if (c.d_poses) (void)hipFree(c.d_poses);
+    if (c.d_part) (void)hipFree(c.d_part);
+    if (c.h_stage) (void)hipHostFree(c.h_stage);
+    c = pg_handle::FramesCache();
+}
+
+// bytes of one frame buffer: rgb [hw,3] | disp [hw] | acc [hw] floats, then the uint8 frame
+size_t frame_bytes(size_t hw) { return hw * 20 + ((hw * 3 + 255) & ~size_t(255)); }
+
+// grow-only: nothing is allocated or freed by a call whose sizes an earlier call has seen
+int frames_cache_ensure(pg_handle* h, size_t hw, int n_frames, size_t part_rays, const float* bg_host, bool staged) {
+    auto& c = h->fc;
+    PG_HIP(h, hipSetDevice(h->device));
+    if (!c.copy_stream) PG_HIP(h, hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < NBUF; ++b) {
+        if (!c.copied[b]) PG_HIP(h, hipEventCreateWithFlags(&c.copied[b], hipEventDisableTiming));
+        if (!c.composed[b]) PG_HIP(h, hipEventCreateWithFlags(&c.composed[b], hipEventDisableTiming));
+    }
+    if (hw > c.hw) {
+        PG_HIP(h, hipDeviceSynchronize());
+        for (int b = 0; b < NBUF; ++b) {
+            if (c.d_frame[b]) { PG_HIP(h, hipFree(c.d_frame[b])); c.d_frame[b] = nullptr; }
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.d_frame[b]), frame_bytes(hw));
+            if (e != hipSuccess) { c.hw = 0; return pg_fail(h, PG_ENOMEM, "frame buffer of %zu bytes failed: %s", frame_bytes(hw), hipGetErrorString(e)); }
+        }
+        c.hw = hw;
+    }
+    if (bg_host) {
+        if (hw > c.bg_hw) {
+            PG_HIP(h, hipDeviceSynchronize());
+            if (c.d_bg) { PG_HIP(h, hipFree(c.d_bg)); c.d_bg = nullptr; c.bg_hw = 0; }
+            PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&c.d_bg), hw * 12));
+            c.bg_hw = hw;
+        }
+        PG_HIP(h, hipMemcpy(c.d_bg, bg_host, hw * 12, hipMemcpyHostToDevice));
+    }
+    if ((size_t)n_frames > c.poses_cap) {
+        PG_HIP(h, hipDeviceSynchronize());
+        if (c.d_poses) { PG_HIP(h, hipFree(c.d_poses)); c.d_poses = nullptr; c.poses_cap = 0; }
+        const size_t cap = (size_t)n_frames + (size_t)n_frames / 2 + 8;
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&c.d_poses), cap * (384 + 8) * sizeof(float)));
+        c.poses_cap = cap;
+    }
+    if (part_rays > c.part_cap) {
+        PG_HIP(h, hipDeviceSynchronize());
+        if (c.d_part) { PG_HIP(h, hipFree(c.d_part)); c.d_part = nullptr; c.part_cap = 0; }
+        const size_t cap = part_rays + part_rays / 4;
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&c.d_part), cap * 20));
+        c.part_cap = cap;
+    }
+    if (staged && NBUF * frame_bytes(hw) > c.stage_bytes) {
+        PG_HIP(h, hipDeviceSynchronize());
+        if (c.h_stage) { PG_HIP(h, hipHostFree(c.h_stage)); c.h_stage = nullptr; c.stage_bytes = 0; }
+        PG_HIP(h, hipHostMalloc(&c.h_stage, NBUF * frame_bytes(hw), hipHostMallocDefault));
+        c.stage_bytes = NBUF * frame_bytes(hw);
+    }
+    return PG_OK;
+}
+
+// page-locked host memory (hipHostMalloc / hipHostRegister, e.g. a torch tensor with pin_memory=True)?
+bool host_pinned(const void* p) {
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Output pipeline of one worker: frame k of the worker composes into device buffer k % NBUF on the render stream
+// while frame k - 1 is copied to the host on the copy stream; nothing blocks the host thread before the call's end
+// (results in pageable memory go through pinned staging and are moved by the worker thread one frame later).
+struct FrameOut {
+    pg_handle* h;
+    hipStream_t st;
+    size_t hw;
+    float* rgbs; float* disps; float* accs; uint8_t* rgb8;
+    bool staged;
+    const float* d_bg;
+    float base_bg;
+    int k = 0;
+    int pend[NBUF];
+    FrameOut(pg_handle* h_, hipStream_t st_, size_t hw_, float* r, float* d, float* a, uint8_t* u8, bool stg, const float* bg, float bb)
+        : h(h_), st(st_), hw(hw_), rgbs(r), disps(d), accs(a), rgb8(u8), staged(stg), d_bg(bg), base_bg(bb) {
+        for (int b = 0; b < NBUF; ++b) pend[b] = -1;
+    }
+    uint8_t* stage(int b) const { return static_cast<uint8_t*>(h->fc.h_stage) + (size_t)b * frame_bytes(hw); }
+    int drain(int b) {              // the staged frame of buffer b -> the caller's (pageable) arrays
+        const int f = pend[b];
+        if (f < 0) return PG_OK;
+        PG_HIP(h, hipEventSynchronize(h->fc.copied[b]));
+        const uint8_t* sp = stage(b);
+        if (rgbs) std::memcpy(rgbs + (size_t)f * hw * 3, sp, hw * 12);
+        if (disps) std::memcpy(disps + (size_t)f * hw, sp + hw * 12, hw * 4);
+        if (accs) std::memcpy(accs + (size_t)f * hw, sp + hw * 16, hw * 4);
+        if (rgb8) std::memcpy(rgb8 + (size_t)f * hw * 3, sp + hw * 20, hw * 3);
+        pend[b] = -1;
+        return PG_OK;
+    }
+    int put(int f, const pgk::FrameGeom& g, const FrameMaps& maps) {
+        auto& c = h->fc;
+        const int b = k++ % NBUF;
+        if (staged) { const int rc = drain(b); if (rc) return rc; }
+        PG_HIP(h, hipStreamWaitEvent(st, c.copied[b], 0));          // buffer b's previous copy-out (no-op before the first)
+        uint8_t* base = reinterpret_cast<uint8_t*>(c.d_frame[b]);
+        float* d_rgb = reinterpret_cast<float*>(base);
+        float* d_disp = reinterpret_cast<float*>(base + hw * 12);
+        float* d_acc = reinterpret_cast<float*>(base + hw * 16);
+        uint8_t* d_u8 = rgb8 ? base + hw * 20 : nullptr;
+        int rc = frame_compose(h, st, g, maps, d_bg, base_bg, d_rgb, d_disp, d_acc, d_u8);
+        if (rc) return rc;
+        PG_HIP(h, hipEventRecord(c.composed[b], st));
+        PG_HIP(h, hipStreamWaitEvent(c.copy_stream, c.composed[b], 0));
+        uint8_t* sp = staged ? stage(b) : nullptr;
+        if (rgbs) PG_HIP(h, hipMemcpyAsync(staged ? (void*)sp : (void*)(rgbs + (size_t)f * hw * 3), d_rgb, hw * 12, hipMemcpyDeviceToHost, c.copy_stream));
+        if (disps) PG_HIP(h, hipMemcpyAsync(staged ? (void*)(sp + hw * 12) : (void*)(disps + (size_t)f * hw), d_disp, hw * 4, hipMemcpyDeviceToHost, c.copy_stream));
+        if (accs) PG_HIP(h, hipMemcpyAsync(staged ? (void*)(sp + hw * 16) : (void*)(accs + (size_t)f * hw), d_acc, hw * 4, hipMemcpyDeviceToHost, c.copy_stream));
+        if (rgb8) PG_HIP(h, hipMemcpyAsync(staged ? (void*)(sp + hw * 20) : (void*)(rgb8 + (size_t)f * hw * 3), d_u8, hw * 3, hipMemcpyDeviceToHost, c.copy_stream));
+        PG_HIP(h, hipEventRecord(c.copied[b], c.copy_stream));
+        if (staged) pend[b] = f;
+        return PG_OK;
+    }
+    int finish() {
+        if (staged)
+            for (int b = 0; b < NBUF; ++b) { const int rc = drain(b); if (rc) return rc; }
+        PG_HIP(h, hipStreamSynchronize(h->fc.copy_stream));
+        return PG_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
 int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws, const float* intrinsics, const int* boxes,
                      float near, float far, const float* skts, const float* cyls, const float* cams, int n_samples,
                      int n_importance, int flags, const float* bg, float base_bg, float* rgbs, float* disps, float* accs,
@@ -1194,14 +1367,33 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
     }
     std::vector<FrameTask> tasks;
     plan_frames(nr, G, h->cfg.chunk, &tasks);
-    // per worker: the frame buffers it composes into and the background (shared by all frames); per task of a
-    // cut frame: a buffer of its own for the range's maps (a worker may hold runs of several frames)
-    struct Worker { pg_handle* h; int rc = PG_OK; float* d_bg = nullptr; std::vector<float*> bufs; };
+    auto whole = [&](const FrameTask& tk) { return tk.r0 == 0 && tk.r1 == nr[tk.frame]; };
+    // Everything a worker needs is set up BEFORE its first launch and kept on its handle between calls (no allocation
+    // in a call whose sizes have been seen): the poses of all frames (one upload), two frame buffers in rotation, the
+    // background, one buffer for the packed maps of the cut-frame ranges it renders, pinned staging when the
+    // caller's result arrays are pageable.
+    const bool staged = !(host_pinned(rgbs) && host_pinned(disps) && host_pinned(accs) && host_pinned(rgb8));
+    std::vector<size_t> part_off(tasks.size(), 0), part_rays(G, 0);
+    std::vector<char> composes(G, 0);
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        const FrameTask& tk = tasks[t];
+        if (whole(tk)) { composes[tk.worker] = 1; continue; }
+        composes[tk.owner] = 1;
+        part_off[t] = part_rays[tk.worker];
+        part_rays[tk.worker] += (size_t)(tk.r1 - tk.r0);
+    }
+    for (int k = 0; k < G; ++k) {
+        const int rc = frames_cache_ensure(wk[k], composes[k] ? hw : 0, n_frames, part_rays[k], composes[k] ? bg : nullptr, staged && composes[k]);
+        if (rc) { (void)hipSetDevice(h->device); return wk[k] == h ? rc : pg_fail(h, rc, "device %d: %s", wk[k]->device, wk[k]->err); }
+    }
+    struct Worker { pg_handle* h; int rc = PG_OK; };
     std::vector<Worker> ws(G);
     for (int k = 0; k < G; ++k) ws[k].h = wk[k];
     std::vector<FrameMaps> maps_of(tasks.size());
-    std::vector<float*> part(tasks.size(), nullptr);
-    auto whole = [&](const FrameTask& tk) { return tk.r0 == 0 && tk.r1 == nr[tk.frame]; };
+    std::vector<FrameOut> outs;
+    outs.reserve(G);
+    for (int k = 0; k < G; ++k)
+        outs.emplace_back(wk[k], wk[k]->own_stream, hw, rgbs, disps, accs, rgb8, staged, bg ? wk[k]->fc.d_bg : nullptr, base_bg);
 
     auto checker = [&](Worker& w) {
         return [&w](hipError_t e, const char* what) {
@@ -1209,66 +1401,36 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
             return e == hipSuccess;
         };
     };
-    // frame buffers + background of a worker that composes
-    auto frame_bufs = [&](Worker& w) {
-        auto check = checker(w);
-        if (!w.bufs.empty()) return true;
-        float *d_rgb = nullptr, *d_disp = nullptr, *d_acc = nullptr;
-        uint8_t* d_rgb8 = nullptr;
-        if (!check(hipMalloc(reinterpret_cast<void**>(&d_rgb), hw * 12), "hipMalloc") ||
-            !check(hipMalloc(reinterpret_cast<void**>(&d_disp), hw * 4), "hipMalloc") ||
-            !check(hipMalloc(reinterpret_cast<void**>(&d_acc), hw * 4), "hipMalloc") ||
-            (rgb8 && !check(hipMalloc(reinterpret_cast<void**>(&d_rgb8), hw * 3), "hipMalloc"))) return false;
-        w.bufs = {d_rgb, d_disp, d_acc, reinterpret_cast<float*>(d_rgb8)};
-        if (bg) {
-            if (!check(hipMalloc(reinterpret_cast<void**>(&w.d_bg), hw * 12), "hipMalloc") ||
-                !check(hipMemcpy(w.d_bg, bg, hw * 12, hipMemcpyHostToDevice), "background upload")) return false;
-        }
-        return true;
-    };
-    auto compose_out = [&](Worker& w, hipStream_t st, int f, const FrameMaps& maps) {
-        auto check = checker(w);
-        float *d_rgb = w.bufs[0], *d_disp = w.bufs[1], *d_acc = w.bufs[2];
-        uint8_t* d_rgb8 = reinterpret_cast<uint8_t*>(w.bufs[3]);
-        w.rc = frame_compose(w.h, st, geo[f], maps, w.d_bg, base_bg, d_rgb, d_disp, d_acc, d_rgb8);
-        if (w.rc) return false;
-        if (rgbs && !check(hipMemcpyAsync(rgbs + (size_t)f * hw * 3, d_rgb, hw * 12, hipMemcpyDeviceToHost, st), "frame download")) return false;
-        if (disps && !check(hipMemcpyAsync(disps + (size_t)f * hw, d_disp, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return false;
-        if (accs && !check(hipMemcpyAsync(accs + (size_t)f * hw, d_acc, hw * 4, hipMemcpyDeviceToHost, st), "frame download")) return false;
-        if (rgb8 && !check(hipMemcpyAsync(rgb8 + (size_t)f * hw * 3, d_rgb8, hw * 3, hipMemcpyDeviceToHost, st), "frame download")) return false;
-        return check(hipStreamSynchronize(st), "hipStreamSynchronize");      // the frame buffers are reused
-    };
-
-    // phase A: every worker renders its tasks; whole frames are composed and copied out at once, the runs of
-    // cut frames stay in their own buffers for the owner
+    // phase A: every worker renders its tasks; whole frames are composed and handed to the output pipeline at once,
+    // the runs of cut frames stay in the worker's range buffer for the owner
     auto phase_a = [&](int k) {
         Worker& w = ws[k];
         pg_handle* hh = w.h;
         auto check = checker(w);
         if (!check(hipSetDevice(hh->device), "hipSetDevice")) return;
         hipStream_t st = hh->own_stream;
+        float* d_skts = hh->fc.d_poses;
+        float* d_cyls = hh->fc.d_poses + (size_t)n_frames * 384;
+        // (pageable sources: the runtime stages them before the calls return; the kernels are ordered behind on `st`)
+        if (!check(hipMemcpyAsync(d_skts, skts, (size_t)n_frames * 384 * sizeof(float), hipMemcpyHostToDevice, st), "pose upload")) return;
+        if (!check(hipMemcpyAsync(d_cyls, cyls, (size_t)n_frames * 5 * sizeof(float), hipMemcpyHostToDevice, st), "cylinder upload")) return;
         for (size_t t = 0; t < tasks.size() && w.rc == PG_OK; ++t) {
             const FrameTask& tk = tasks[t];
             if (tk.worker != k) continue;
             const int f = tk.frame;
-            // pose of the frame (skts may hold one pose for all frames: n_poses is not passed, F poses are)
-            if (!check(hipMemcpyAsync(hh->d_pose, skts + (size_t)f * 384, 384 * sizeof(float), hipMemcpyHostToDevice, st), "pose upload")) return;
-            if (!check(hipMemcpyAsync(hh->d_pose + 384, cyls + (size_t)f * 5, 5 * sizeof(float), hipMemcpyHostToDevice, st), "cylinder upload")) return;
-            if (!check(hipStreamSynchronize(st), "hipStreamSynchronize")) return;      // the host rows may be pageable
             if (whole(tk)) {
-                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t]);
+                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, d_skts + (size_t)f * 384, d_cyls + (size_t)f * 5, n_samples, n_importance, flags, &maps_of[t]);
                 if (w.rc) return;
-                if (!frame_bufs(w) || !compose_out(w, st, f, maps_of[t])) return;
+                w.rc = outs[k].put(f, geo[f], maps_of[t]);
             } else {
                 const size_t n = (size_t)(tk.r1 - tk.r0);
                 if (n == 0) continue;
-                if (!check(hipMalloc(reinterpret_cast<void**>(&part[t]), n * 20), "hipMalloc")) return;
-                const FrameMaps ext{part[t], part[t] + n * 3, part[t] + n * 4};
-                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, hh->d_pose, hh->d_pose + 384, n_samples, n_importance, flags, &maps_of[t], &ext);
-                if (w.rc) return;
+                float* part = hh->fc.d_part + part_off[t] * 5;
+                const FrameMaps ext{part, part + n * 3, part + n * 4};
+                w.rc = frame_render_range(hh, st, geo[f], tk.r0, tk.r1, d_skts + (size_t)f * 384, d_cyls + (size_t)f * 5, n_samples, n_importance, flags, &maps_of[t], &ext);
             }
         }
-        check(hipStreamSynchronize(st), "hipStreamSynchronize");
+        if (w.rc == PG_OK) check(hipStreamSynchronize(st), "hipStreamSynchronize");      // phase B reads other workers' range buffers
     };
     // phase B: the owner of a cut frame gathers all its runs (device to device), composes, copies out
     auto phase_b = [&](int k) {
@@ -1295,8 +1457,14 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
                     !check(hipMemcpyPeerAsync(box.disp_map + pt.r0, hh->device, maps_of[u].disp_map, src_dev, n * 4, st), "peer copy") ||
                     !check(hipMemcpyPeerAsync(box.acc_map + pt.r0, hh->device, maps_of[u].acc_map, src_dev, n * 4, st), "peer copy")) return;
             }
-            if (!frame_bufs(w) || !compose_out(w, st, f, box)) return;
+            w.rc = outs[k].put(f, geo[f], box);
         }
+    };
+    auto finish = [&](int k) {
+        Worker& w = ws[k];
+        if (w.rc != PG_OK || !composes[k]) return;
+        if (!checker(w)(hipSetDevice(w.h->device), "hipSetDevice")) return;
+        w.rc = outs[k].finish();
     };
     auto run = [&](auto&& fn) {
         std::vector<std::thread> th;
@@ -1310,14 +1478,14 @@ int pg_render_frames(pg_handle* h, int n_frames, int H, int W, const float* c2ws
     bool ok = true;
     for (const Worker& w : ws) ok = ok && w.rc == PG_OK;
     if (ok && split) run(phase_b);
+    run(finish);
     int rc = PG_OK;
-    for (size_t t = 0; t < tasks.size(); ++t)
-        if (part[t]) { (void)hipSetDevice(wk[tasks[t].worker]->device); (void)hipFree(part[t]); }
     for (Worker& w : ws) {
-        (void)hipSetDevice(w.h->device);
-        for (float* b : w.bufs) if (b) (void)hipFree(b);
-        if (w.d_bg) (void)hipFree(w.d_bg);
-        if (w.rc && rc == PG_OK) rc = (w.h == h) ? w.rc : pg_fail(h, w.rc, "device %d: %s", w.h->device, w.h->err);
+        if (w.rc != PG_OK) {        // nothing of a failed call may still be in flight when the caller's arrays go away
+            (void)hipSetDevice(w.h->device);
+            (void)hipDeviceSynchronize();
+            if (rc == PG_OK) rc = (w.h == h) ? w.rc : pg_fail(h, w.rc, "device %d: %s", w.h->device, w.h->err);
+        }
     }
     (void)hipSetDevice(h->device);
     return rc;

@@ -45,6 +45,8 @@ struct pg_handle {
     size_t sc_part_cap = 0;          // ... doubles
     uint8_t* rec = nullptr;          // per-ray records of the factorised 16-bit path: Y [n + pad, 8 KiB] then (a, b) [n + pad, 768 B]
     size_t rec_bytes = 0;
+    long long rec_pad_n = -1;        // (n, Y bytes per ray) whose padding records are currently zero (-1: none)
+    int rec_pad_y = 0;
     // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
     // further device; every handle has a stream and a small pose buffer of its own for that path
     std::vector<pg_handle*> peers;
@@ -54,8 +56,28 @@ struct pg_handle {
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_aux;      // the record kernel in front of a factorised launch
+    int64_t aux_n = 0;               // record launches / their device time already folded in by a pg_profile_read
+    double aux_ms = 0.0;
     int64_t prof_points = 0;
     void* train = nullptr;           // the training tape (pg_train.hip): activations of the last pg_train_forward
+    // pg_render_frames: per-device buffers kept between calls (frames of H x W pixels, background, pinned staging)
+    struct FramesCache {
+        size_t hw = 0;               // pixels the frame buffers were sized for
+        bool has_u8 = false;
+        static constexpr int NBUF = 2;               // frame buffers in rotation: frame k+1 composes while frame k copies out
+        float* d_frame[NBUF] = {};                   // rgb [hw,3] | disp [hw] | acc [hw] (| rgb8 [hw,3] bytes behind)
+        hipEvent_t composed[NBUF] = {};              // buffer b holds a finished frame (render stream)
+        hipEvent_t copied[NBUF] = {};                // the device-to-host copy out of buffer b has finished (copy stream)
+        hipStream_t copy_stream = nullptr;
+        float* d_bg = nullptr;                       // background [hw,3] (uploaded per call when given)
+        size_t bg_hw = 0;
+        float* d_poses = nullptr;                    // skts + cyls of all frames of the call: [F, 384 + 8]
+        size_t poses_cap = 0;                        // ... frames
+        float* d_part = nullptr;                     // packed maps (20 B per ray) of the ray ranges of cut frames this device renders
+        size_t part_cap = 0;                         // ... rays
+        void* h_stage = nullptr;                     // pinned host staging of NBUF frames (results that land in pageable memory)
+        size_t stage_bytes = 0;
+    } fc;
 };
 
 extern "C" void pg_train_release(pg_handle* h);

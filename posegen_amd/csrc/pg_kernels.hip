@@ -291,12 +291,20 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// act_fn of raw2outputs (get_density_fn, core/raycasters.py:230-238): F.relu, or F.softplus(x - shift, beta=1) with
+// torch's threshold of 20 (the linear branch above it)
+__device__ __forceinline__ float density_act(float x, int act, float shift) {
+    if (act == 0) return fmaxf(x, 0.0f);
+    const float t = x - shift;
+    return t > 20.0f ? t : log1pf(expf(t));
+}
+
 // one ray by one wave (sh_*: the wave's rows of the workgroup's LDS arrays)
 __device__ __forceinline__ void composite_ray(
         const long long ray, const int lane, const int wave,
         float (*sh_w)[CP_MAXS], float (*sh_z)[CP_MAXS + CP_MAXI], float (*sh_cdf)[CP_MAXS],
         const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ raw,
-        int S, float density_scale, float rgb_eps,
+        int S, float density_scale, float rgb_eps, int act, float act_shift,
         float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
         float* __restrict__ alpha_out, float* __restrict__ w_out,
         int n_imp, float* __restrict__ z_fine, const float* __restrict__ noise, const float* __restrict__ u_rand,
@@ -318,7 +326,7 @@ __device__ __forceinline__ void composite_ray(
             const float zs = zr[s];
             const float delta = (s + 1 < S ? zr[s + 1] - zs : 1e10f) * dnorm;
             // raw2alpha(raw / B + noise): `noise` [n,S] is the caller's draw (training, nerf.py:175-186), else 0
-            const float sig = fmaxf(q.w / density_scale + (noise ? noise[ray * S + s] : 0.0f), 0.0f);
+            const float sig = density_act(q.w / density_scale + (noise ? noise[ray * S + s] : 0.0f), act, act_shift);
             a_[e] = 1.0f - expf(-sig * delta);
             z_[e] = zs;
             const float k = 1.0f + 2.0f * rgb_eps;
@@ -449,7 +457,7 @@ __device__ __forceinline__ void composite_ray(
 // (262 144 one-ray waves per 512 x 512 launch are bound by the rate waves can be dispatched, not by their 2 KB of traffic).
 __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
         const float* __restrict__ rays, const float* __restrict__ z, const float4* __restrict__ raw,
-        long long n, int S, float density_scale, float rgb_eps,
+        long long n, int S, float density_scale, float rgb_eps, int act, float act_shift,
         float* __restrict__ rgb_out, float* __restrict__ disp_out, float* __restrict__ acc_out,
         float* __restrict__ alpha_out, float* __restrict__ w_out,
         int n_imp, float* __restrict__ z_fine, const float* __restrict__ noise, const float* __restrict__ u_rand,
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(CP_WAVES * 64) void composite_kernel(
     __shared__ float sh_cdf[CP_WAVES][CP_MAXS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (long long ray = (long long)blockIdx.x * CP_WAVES + wave; ray < n; ray += (long long)gridDim.x * CP_WAVES) {
-        composite_ray(ray, lane, wave, sh_w, sh_z, sh_cdf, rays, z, raw, S, density_scale, rgb_eps, rgb_out, disp_out, acc_out,
+        composite_ray(ray, lane, wave, sh_w, sh_z, sh_cdf, rays, z, raw, S, density_scale, rgb_eps, act, act_shift, rgb_out, disp_out, acc_out,
                       alpha_out, w_out, n_imp, z_fine, noise, u_rand, order);
         PG_WAVE_SYNC();                         // the wave's LDS rows are reused by its next ray
     }
@@ -725,15 +733,15 @@ extern "C" int pg_launch_sample_coarse(const float* rays, const float* cyls, lon
 }
 
 extern "C" int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
-                                   float density_scale, float rgb_eps, float* rgb, float* disp, float* acc,
-                                   float* alpha, float* weights, int n_imp, float* z_fine, const float* noise,
+                                   float density_scale, float rgb_eps, int density_act, float act_shift, float* rgb, float* disp,
+                                   float* acc, float* alpha, float* weights, int n_imp, float* z_fine, const float* noise,
                                    const float* u_rand, int* order, void* stream) {
     if (n <= 0) return 0;
     long long blocks = (n + pgk::CP_WAVES - 1) / pgk::CP_WAVES;
     if (blocks > 16384) blocks = 16384;         // a wave takes several rays (measured flat from 4 k to 32 k blocks, -0.05 ms per frame against one ray per wave)
     hipLaunchKernelGGL(pgk::composite_kernel, dim3((unsigned)blocks), dim3(pgk::CP_WAVES * 64), 0,
                        static_cast<hipStream_t>(stream), rays, z, reinterpret_cast<const float4*>(raw), n, S,
-                       density_scale, rgb_eps, rgb, disp, acc, alpha, weights, n_imp, z_fine, noise, u_rand, order);
+                       density_scale, rgb_eps, density_act, act_shift, rgb, disp, acc, alpha, weights, n_imp, z_fine, noise, u_rand, order);
     return (int)hipGetLastError();
 }
 

@@ -10,11 +10,12 @@
 // core/utils/ray_utils.py:285); poses, rays and the embedder's cutoff parameters get no gradient (the reference's
 // cutoff_dist has requires_grad=False; pose optimisation is out of scope).
 //
-// This is the first slice: exact fp32 arithmetic, correctness before speed.  Training batches are small (N_rand =
-// 2048 rays -> 131 k + 164 k points, configs/surreal/surreal.txt:34), so the 1080-wide embedding and the layer
-// activations are MATERIALISED in HBM (14 KB per point, 4 GB per batch -- 1.4 % of the card) and every layer is a
-// plain fp32 GEMM (a register-tiled FMA kernel with split-K for the weight gradients; the fp32 MFMA has the same
-// peak as the fp32 VALU on gfx950).  The fused inference kernels are not involved.
+// Exact fp32 arithmetic.  Training batches are small (N_rand = 2048 rays -> 131 k + 164 k points,
+// configs/surreal/surreal.txt:34), so the 1080-wide embedding and the layer activations are MATERIALISED in HBM
+// (14 KB per point, 4 GB per batch -- 1.4 % of the card) and every layer is a plain fp32 GEMM on
+// v_mfma_f32_32x32x2_f32 (128 x 128 x 16 tiles for the trunk shapes, a 64-tile kernel for the heads and unaligned
+// shapes); the weight gradients split K over the points and are reduced in a fixed order (bitwise repeatable).  The
+// fused inference kernels are not involved.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -28,8 +29,8 @@ int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_
                             int S, int lindisp, float* near_far, float* z, const float* t_rand, double* scratch, void* stream);
 int pg_launch_gather_noise(const float* src, long long n, int stride, int S, const int* order, float* dst, void* stream);
 int pg_launch_composite(const float* rays, const float* z, const float* raw, long long n, int S,
-                        float density_scale, float rgb_eps, float* rgb, float* disp, float* acc, float* alpha,
-                        float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
+                        float density_scale, float rgb_eps, int density_act, float act_shift, float* rgb, float* disp, float* acc,
+                        float* alpha, float* weights, int n_imp, float* z_fine, const float* noise, const float* u_rand, int* order,
                         void* stream);
 int pg_composite_max_samples(void);
 int pg_composite_max_importance(void);
@@ -330,14 +331,18 @@ __global__ __launch_bounds__(256) void code_scatter_kernel(const float* __restri
 
 // ---- backward of raw2outputs (core/networks/nerf.py:150-205), one thread per ray ---------------------------------
 // forward: delta_i = (z_{i+1} - z_i) |d| (last 1e10 |d|); c_i = sigmoid(raw_rgb) (1 + 2 eps) - eps;
-// s_i = relu(raw_sigma / B + noise); a_i = 1 - exp(-s_i delta_i); T_i = prod_{k<i} (1 - a_k + 1e-10); w_i = a_i T_i;
+// s_i = act(raw_sigma / B + noise) (relu or shifted softplus); a_i = 1 - exp(-s_i delta_i); T_i = prod_{k<i} (1 - a_k + 1e-10); w_i = a_i T_i;
 // rgb_map = sum w_i c_i; acc_map = min(sum w_i, 1).  Given d_rgb [n,3] and d_acc [n] (or null):
 // g_i = dL/dw_i = d_rgb . c_i + d_acc [sum w < 1];  dL/da_i = g_i T_i - (sum_{k>i} g_k w_k) / (1 - a_i + 1e-10).
 __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restrict__ rays, const float* __restrict__ z,
                                                           const float* __restrict__ raw, const float* __restrict__ noise,
-                                                          long long n, int S, float density_scale, float rgb_eps,
+                                                          long long n, int S, float density_scale, float rgb_eps, int act, float act_shift,
                                                           const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
                                                           float* __restrict__ d_raw) {
+    // act_fn of raw2outputs and its derivative (get_density_fn, core/raycasters.py:230-238): relu, or
+    // softplus(x - shift) with torch's linear branch above 20
+    auto actf = [&](float x) { if (act == 0) return fmaxf(x, 0.0f); const float t = x - act_shift; return t > 20.0f ? t : log1pf(expf(t)); };
+    auto dact = [&](float x) { if (act == 0) return x > 0.0f ? 1.0f : 0.0f; const float t = x - act_shift; return t > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-t)); };
     const long long r = blockIdx.x * 64ll + threadIdx.x;
     if (r >= n) return;
     const float* rb = rays + r * 11;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
     float T = 1.0f, wsum = 0.0f;
     for (int i = 0; i < S; ++i) {
         const float delta = (i + 1 < S ? zr[i + 1] - zr[i] : 1e10f) * dn;
-        const float s = fmaxf(rw[i * 4 + 3] / density_scale + (nz ? nz[i] : 0.0f), 0.0f);
+        const float s = actf(rw[i * 4 + 3] / density_scale + (nz ? nz[i] : 0.0f));
         const float a = 1.0f - expf(-s * delta);
         wsum += a * T;
         T *= 1.0f - a + 1e-10f;
@@ -364,14 +369,14 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
     for (int i = 0; i < S; ++i) {
         Tl[i] = T;
         const float delta = (i + 1 < S ? zr[i + 1] - zr[i] : 1e10f) * dn;
-        const float s = fmaxf(rw[i * 4 + 3] / density_scale + (nz ? nz[i] : 0.0f), 0.0f);
+        const float s = actf(rw[i * 4 + 3] / density_scale + (nz ? nz[i] : 0.0f));
         T *= 1.0f - (1.0f - expf(-s * delta)) + 1e-10f;
     }
     float suffix = 0.0f;        // sum_{k>i} g_k w_k
     for (int i = S - 1; i >= 0; --i) {
         const float delta = (i + 1 < S ? zr[i + 1] - zr[i] : 1e10f) * dn;
         const float pre = rw[i * 4 + 3] / density_scale + (nz ? nz[i] : 0.0f);
-        const float s = fmaxf(pre, 0.0f);
+        const float s = actf(pre);
         const float e = expf(-s * delta);
         const float a = 1.0f - e;
         const float w = a * Tl[i];
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
         dr[i * 4] = gr * w * k * sr * (1.0f - sr);
         dr[i * 4 + 1] = gg * w * k * sg * (1.0f - sg);
         dr[i * 4 + 2] = gb * w * k * sb * (1.0f - sb);
-        dr[i * 4 + 3] = pre > 0.0f ? dA * delta * e / density_scale : 0.0f;
+        const float da = dact(pre);
+        dr[i * 4 + 3] = da > 0.0f ? dA * delta * e * da / density_scale : 0.0f;
         suffix += g * w;
     }
 }
@@ -398,6 +404,7 @@ struct Tape {
     uint8_t* buf = nullptr;
     size_t bytes = 0;
     bool valid = false;
+    int64_t generation = 0;     // id of the forward pass the tape holds (pg_train_forward returns it, pg_train_backward checks it)
     long long n = 0;
     int S = 0, N = 0, fc = 0;
     float *rays = nullptr, *cams = nullptr;
@@ -579,7 +586,8 @@ void pg_train_release(pg_handle* h) {
 
 int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_batch, const float* skts, int64_t pose_stride,
                      const float* cyls, int64_t cyl_stride, const float* cams, int n_samples, int n_importance, int flags,
-                     const pg_train_draws* dr, const pg_net_params* coarse, const pg_net_params* fine, const pg_outputs* out) {
+                     const pg_train_draws* dr, const pg_net_params* coarse, const pg_net_params* fine, const pg_outputs* out,
+                     int64_t* tape_id) {
     using namespace pgt;
     if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
     if (n <= 0 || !ray_batch || !skts || !cyls || !coarse || !out) return pg_fail(h, PG_EINVAL, "pg_train_forward: null / non-positive argument");
@@ -666,7 +674,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     if (embed(pc, codes_dev[0], coarse->n_codes) != hipSuccess) return pg_fail(h, PG_EHIP, "embedding kernel launch failed");
     PG_TRY(mlp_forward(h, s, pc, *coarse, fc));
     const bool hier = N > 0;
-    e = pg_launch_composite(t.rays, pc.z, pc.raw, n, S, h->cfg.density_scale, h->cfg.rgb_eps, hier ? out->rgb0 : out->rgb_map,
+    e = pg_launch_composite(t.rays, pc.z, pc.raw, n, S, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, hier ? out->rgb0 : out->rgb_map,
                             hier ? out->disp0 : out->disp_map, hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
                             out->weights0 ? out->weights0 : w0, N, hier ? t.pass[1].z : nullptr, (dr && dr->noise0) ? pc.noise : nullptr,
                             dr ? dr->u_rand : nullptr, (rnoise && hier) ? order : nullptr, stream);
@@ -682,7 +690,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
         }
         if (embed(pf, codes_dev[1], fine->n_codes) != hipSuccess) return pg_fail(h, PG_EHIP, "embedding kernel launch failed");
         PG_TRY(mlp_forward(h, s, pf, *fine, fc));
-        e = pg_launch_composite(t.rays, pf.z, pf.raw, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, out->rgb_map, out->disp_map, out->acc_map,
+        e = pg_launch_composite(t.rays, pf.z, pf.raw, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, out->rgb_map, out->disp_map, out->acc_map,
                                 out->alpha, nullptr, 0, nullptr, pf.noise, nullptr, nullptr, stream);
         if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -692,22 +700,30 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     if (hier && out->z_fine) PG_HIP(h, hipMemcpyAsync(out->z_fine, t.pass[1].z, (size_t)Pf * 4, hipMemcpyDeviceToDevice, s));
     if (hier && out->raw_fine) PG_HIP(h, hipMemcpyAsync(out->raw_fine, t.pass[1].raw, (size_t)Pf * 16, hipMemcpyDeviceToDevice, s));
     t.valid = true;
+    t.generation += 1;
+    if (tape_id) *tape_id = t.generation;
     return PG_OK;
 }
 
-int pg_train_backward(pg_handle* h, void* stream, const float* d_rgb_map, const float* d_acc_map, const float* d_rgb0,
+int pg_train_backward(pg_handle* h, void* stream, int64_t tape_id, const float* d_rgb_map, const float* d_acc_map, const float* d_rgb0,
                       const float* d_acc0, const pg_net_grads* coarse, const pg_net_grads* fine) {
     using namespace pgt;
     if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
     if (!h->train || !static_cast<Tape*>(h->train)->valid) return pg_fail(h, PG_ESTATE, "pg_train_backward: no forward pass on the tape (pg_train_forward)");
     Tape& t = *static_cast<Tape*>(h->train);
+    // ONE forward is outstanding per handle: a later pg_train_forward reuses the tape, and its activations must not be
+    // taken for those of the pass this backward belongs to (two batches summed into one loss, a delayed backward)
+    if (tape_id != t.generation)
+        return pg_fail(h, PG_ESTATE, "pg_train_backward: the tape of forward pass %lld has been overwritten by forward pass %lld "
+                       "(one outstanding pg_train_forward per handle: run backward before the next forward)",
+                       (long long)tape_id, (long long)t.generation);
     if (!coarse || (t.has_fine && !fine)) return pg_fail(h, PG_EINVAL, "pg_train_backward: null gradient struct");
     PG_HIP(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     auto run = [&](int k, const float* d_rgb, const float* d_acc, const pg_net_grads& g) -> int {
         const Pass& p = t.pass[k];
         hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((t.n + 63) / 64)), dim3(64), 0, s, t.rays, p.z, p.raw, p.noise, (long long)t.n, p.S,
-                           h->cfg.density_scale, h->cfg.rgb_eps, d_rgb, d_acc, t.d_raw);
+                           h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, d_rgb, d_acc, t.d_raw);
         PG_LAUNCH_CHECK(h, "composite backward");
         return mlp_backward(h, s, t, p, t.params[k], g);
     };

@@ -27,6 +27,14 @@ NET_TENSOR_ORDER = ([f"pts_linears.{l}.{k}" for l in range(8) for k in ("weight"
                        for k in ("weight", "bias")])
 
 
+def _density_act(density_type: str) -> int:
+    """--density_type -> PG_ACT_* (get_density_fn, core/raycasters.py:230-238 raises on anything else)."""
+    try:
+        return {"relu": _ffi.PG_ACT_RELU, "softplus": _ffi.PG_ACT_SOFTPLUS}[density_type]
+    except KeyError:
+        raise NotImplementedError(f"density activation {density_type} is undefined") from None
+
+
 def _np32(x) -> np.ndarray:
     if isinstance(x, torch.Tensor):
         x = x.detach().cpu().numpy()
@@ -65,7 +73,8 @@ class HipRenderer:
                            skip_layer=cfg.skips[0], view_width=cfg.net_width // 2,
                            framecode_ch=cfg.framecode_ch, n_framecodes=cfg.n_framecodes, chunk=cfg.chunk,
                            precision=self.precision, cutoff_dist=cfg.cutoff_dist,
-                           density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps, reserved0=0.0)
+                           density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps,
+                           softplus_shift=float(cfg.softplus_shift), density_act=_density_act(cfg.density_type), reserved0=0)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         dev_ids = [idx] if devices is None else devices
         ids = (C.c_int * len(dev_ids))(*dev_ids)
@@ -373,10 +382,13 @@ class HipRenderer:
             raise ValueError(f"need one pose per frame: {sk.shape[0]} skts / {cy.shape[0]} cyls for {F} frames")
         cm = None if cams is None else _np32(cams).reshape(-1)
         bgh = None if bg is None else _np32(bg).reshape(H * W, 3)
-        rgbs = np.empty((F, H, W, 3), dtype=np.float32)
-        disps = np.empty((F, H, W, 1), dtype=np.float32)
-        accs = np.empty((F, H, W, 1), dtype=np.float32)
-        rgb8 = np.empty((F, H, W, 3), dtype=np.uint8) if want_uint8 else None
+        # results in page-locked memory when they are small enough to pin as a whole: the library then copies every
+        # frame straight into them on a copy stream while the next one renders; pageable arrays (long paths) are
+        # filled through the library's own pinned staging
+        pin = F * H * W * (23 if want_uint8 else 20) <= (256 << 20) and torch.cuda.is_available()
+        new = lambda c, dt: torch.empty((F, H, W, c), dtype=dt, pin_memory=pin).numpy()
+        rgbs, disps, accs = new(3, torch.float32), new(1, torch.float32), new(1, torch.float32)
+        rgb8 = new(3, torch.uint8) if want_uint8 else None
         hp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
         self._check(self.lib.pg_render_frames(
             self.handle, F, int(H), int(W), hp(c2w_h), hp(intr), hp(bx), float(near), float(far), hp(sk), hp(cy), hp(cm),
@@ -608,6 +620,16 @@ class HipRayCaster:
             raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
         if skts is None or cyls is None:
             raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
+        # refuse, don't render differently: a caller configured for anything the fused kernels do not compute
+        if nerf_type != "nerf":
+            raise NotImplementedError(f"nerf_type={nerf_type!r}: only 'nerf' is on the HIP path")
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False: the HIP kernels always evaluate the view branch (nerf.py:112-121)")
+        if network_fine is not None:
+            raise NotImplementedError("network_fine: the caster renders with the nets it was loaded with (load_state_dict)")
+        if unused:
+            raise TypeError(f"HipRayCaster.forward: unexpected keyword arguments {sorted(unused)}")
+        self._check_preproc_kwargs(preproc_kwargs)
         # One call = one nanmean group, like get_near_far_in_cylinder on the reference's ray_batch
         # (ray_utils.py:292-344): only batchify_rays / render_path split a frame into `chunk` groups.
         # The group size is a property of THIS call: the renderer's own setting (what later direct
@@ -625,6 +647,39 @@ class HipRayCaster:
                                              want_alpha=want_alpha, extras=extras, draws=draws)
         finally:
             self.renderer.set_chunk(keep)
+
+    # the reference's preproc_kwargs (core/raycasters.py:140-152): the encoder objects and the density function
+    # `create_raycaster` picked.  The kernels implement exactly one choice of each.
+    _ENCODERS = {"pts_tr_fn": "WorldToLocalEncoder", "kp_input_fn": "RelDistEncoder",
+                 "view_input_fn": "VecNormEncoder", "bone_input_fn": "VecNormEncoder"}
+
+    def _check_preproc_kwargs(self, pk):
+        if not pk:
+            return
+        cfg = self.cfg
+        unknown = set(pk) - set(self._ENCODERS) - {"density_scale", "density_fn"}
+        if unknown:
+            raise NotImplementedError(f"preproc_kwargs {sorted(unknown)} are not supported by the HIP renderer")
+        for key, want in self._ENCODERS.items():
+            fn = pk.get(key)
+            if fn is not None and type(fn).__name__ != want:
+                raise NotImplementedError(f"preproc_kwargs[{key!r}] is a {type(fn).__name__}; the HIP kernels compute {want} only")
+        ds = pk.get("density_scale")
+        if ds is not None and float(ds) != float(cfg.density_scale):
+            raise ValueError(f"preproc_kwargs['density_scale']={float(ds)} but the caster was created with "
+                             f"density_scale={cfg.density_scale} (RenderConfig)")
+        dfn = pk.get("density_fn")
+        if dfn is not None:
+            # any callable may arrive here (get_density_fn returns F.relu or a lambda): compare it with the
+            # configured activation on probe values instead of guessing from its identity
+            x = torch.tensor([-30., -2., -0.25, 0., 0.5, 1., 3., 25.])
+            want = torch.relu(x) if cfg.density_type == "relu" else torch.nn.functional.softplus(x - cfg.softplus_shift, beta=1)
+            got = torch.as_tensor(dfn(x)).detach().float().cpu()
+            if got.shape != want.shape or not torch.allclose(got, want, rtol=1e-6, atol=1e-7):
+                raise NotImplementedError(
+                    f"preproc_kwargs['density_fn'] is not the configured density activation (density_type={cfg.density_type!r}"
+                    + (f", softplus_shift={cfg.softplus_shift}" if cfg.density_type != "relu" else "")
+                    + "): create the caster with the matching RenderConfig")
 
     def training_draws(self, n, S, N, perturb=0., raw_noise_std=0., ray_noise_std=0., pytest=False):
         return make_training_draws(n, S, N, perturb, raw_noise_std, ray_noise_std, pytest=pytest,
@@ -671,7 +726,8 @@ def create_raycaster(cfg: RenderConfig, ckpt=None, device="cuda:0", precision=PR
     caster.eval()
     return {"ray_caster": caster, "perturb": False, "N_importance": cfg.n_importance,
             "N_samples": cfg.n_samples, "use_viewdirs": True, "raw_noise_std": 0., "ray_noise_std": 0.,
-            "ext_scale": cfg.ext_scale, "preproc_kwargs": {}, "lindisp": cfg.lindisp, "nerf_type": "nerf"}
+            "ext_scale": cfg.ext_scale, "preproc_kwargs": {"density_scale": cfg.density_scale}, "lindisp": cfg.lindisp,
+            "nerf_type": "nerf"}
 
 
 def find_checkpoint(basedir: str, expname: str, ft_path: Optional[str] = None, no_reload: bool = False) -> Optional[str]:

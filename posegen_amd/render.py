@@ -14,7 +14,13 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .rays import get_rays, kp_to_boxes, kp_to_valid_rays
+from .rays import BoxPixelIds, frame_boxes, get_rays, kp_to_boxes, kp_to_valid_rays
+
+
+# render_path: results of up to this many bytes are page-locked as a whole; longer paths go through a ring of
+# PINNED_RING page-locked frames (hundreds of megapixel frames must not pin gigabytes)
+PINNED_RESULT_BYTES = 256 << 20
+PINNED_RING = 3
 
 
 def _caster_device(ray_caster):
@@ -94,11 +100,15 @@ def render_frames_device(render_poses, hwf, chunk, render_kwargs, centers=None, 
     if kp is None and cyls is None:
         raise NotImplementedError("render_path needs kp or cyls (bounding-cylinder cull)")
     r, dev = _caster_device(render_kwargs["ray_caster"])
-    # Boxes on the host (float64 numpy like the reference); rays, rendering and the scatter into
-    # the background frame on the device (pg_render_frame): no per-frame meshgrid, no ray copies.
-    cyls, bboxes, grids = boxes if boxes is not None else kp_to_boxes(
-        render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale, centers=centers)
-    valid_idxs = [rows * w + cols for rows, cols, _, w, _, _, _ in grids]
+    # Boxes, rays, rendering and the scatter into the background frame on the device (pg_pose_boxes,
+    # pg_render_frame): no per-frame meshgrid, no ray copies.
+    if boxes is not None:
+        cyls, bboxes, grids = boxes
+        meta = [g[2:] for g in grids]
+    else:                       # (boxes from the device when the call allows it; the pixel ids only if someone reads them)
+        cyls, bboxes, meta = frame_boxes(r, render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale,
+                                         centers=centers)
+    valid_idxs = BoxPixelIds(bboxes, [m[1] for m in meta])
     ids = list(range(len(render_poses))) if frame_ids is None else list(frame_ids)
     rgbs, disps, accs = [], [], []
     kw = render_kwargs
@@ -109,8 +119,10 @@ def render_frames_device(render_poses, hwf, chunk, render_kwargs, centers=None, 
         skts = skts.to(dev, dtype=torch.float32)
     if cyls is not None:
         cyls = torch.as_tensor(cyls).to(dev, dtype=torch.float32)
+    if cams is not None:        # frame-code indices on the host once (a per-frame float() of a device tensor would block)
+        cams = torch.as_tensor(cams).detach().float().cpu()
     for k, i in enumerate(ids):
-        _, _, h, w, f, c2w_np, center = grids[i]
+        h, w, f, c2w_np, center = meta[i]
         bg = None
         if bg_imgs is not None and not white_bkgd:
             import torch.nn.functional as F
@@ -120,7 +132,7 @@ def render_frames_device(render_poses, hwf, chunk, render_kwargs, centers=None, 
         cam = _pick(cams, i)
         rgb_img, disp_img, acc_img = r.render_frame(
             h, w, f, c2w_np, bboxes[i], _pick(skts, i), _pick(cyls, i), center=center,
-            cam=None if cam is None else float(torch.as_tensor(cam).reshape(-1)[0]),
+            cam=None if cam is None else float(cam.reshape(-1)[0]),
             n_samples=kw.get("N_samples"), n_importance=kw.get("N_importance"), lindisp=bool(kw.get("lindisp", False)),
             bg=bg, base_bg=1.0 if white_bkgd else 0.0)
         if frame_sink is not None:
@@ -165,33 +177,84 @@ def render_path(render_poses, hwf, chunk, render_kwargs, centers=None, kp=None, 
             bg_indices=bg_indices, cams=cams, render_factor=render_factor, white_bkgd=white_bkgd, ext_scale=ext_scale,
             frame_ids=frame_ids)
         return (rgbs.cpu().numpy(), disps.cpu().numpy(), accs.cpu().numpy() if ret_acc else [], valid_idxs, bboxes)
-    # Frames go to the host while the next ones render: pinned result arrays (torch's caching host allocator hands
-    # the blocks back when the returned numpy arrays die), one copy stream, a copy per frame ordered behind that
-    # frame's kernels by an event.  (Pageable copies of the stacked frames at the end were 3.6 ms per 512 x 512 frame.)
     if render_factor:
         H, W = int(H) // render_factor, int(W) // render_factor
-    H, W = int(H), int(W)
-    host = [torch.empty((n_out, H, W, c), dtype=torch.float32, pin_memory=True) for c in ((3, 1, 1) if ret_acc else (3, 1))]
-    copy_stream = torch.cuda.Stream(device=dev)
-    keep = []
-
-    def sink(k, rgb, disp, acc):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        keep.append((rgb, disp, acc))                   # alive until the copies have run
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(ev)
-            host[0][k].copy_(rgb.view(H, W, 3), non_blocking=True)
-            host[1][k].copy_(disp.view(H, W, 1), non_blocking=True)
-            if ret_acc:
-                host[2][k].copy_(acc.view(H, W, 1), non_blocking=True)
-
+    dl = FrameDownloader(n_out, int(H), int(W), ret_acc, dev)
     _, _, _, valid_idxs, bboxes = render_frames_device(
         render_poses, hwf, chunk, render_kwargs, centers=centers, kp=kp, skts=skts, cyls=cyls, bg_imgs=bg_imgs,
         bg_indices=bg_indices, cams=cams, render_factor=render_factor, white_bkgd=white_bkgd, ext_scale=ext_scale,
-        frame_ids=frame_ids, frame_sink=sink)
-    copy_stream.synchronize()
-    return (host[0].numpy(), host[1].numpy(), host[2].numpy() if ret_acc else [], valid_idxs, bboxes)
+        frame_ids=frame_ids, frame_sink=dl.sink)
+    res = dl.finish()
+    return (res[0], res[1], res[2] if ret_acc else [], valid_idxs, bboxes)
+
+
+class FrameDownloader:
+    """Frames go to the host while the next ones render: a copy stream, one copy per frame ordered behind that
+    frame's kernels by an event.  (Pageable copies of the stacked frames at the end were 3.6 ms per 512 x 512 frame.)
+    `sink(k, rgb, disp, acc)` takes the k-th frame's device tensors, `finish()` returns the numpy stacks
+    [rgbs [n,H,W,3], disps [n,H,W,1] (, accs [n,H,W,1])]."""
+
+    def __init__(self, n_out: int, H: int, W: int, ret_acc: bool, dev):
+        self.H, self.W, self.dev = H, W, dev
+        self.chans = (3, 1, 1) if ret_acc else (3, 1)
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        per_frame = H * W * sum(self.chans) * 4
+        self.whole = n_out * per_frame <= PINNED_RESULT_BYTES
+        if self.whole:
+            # short paths: the results themselves are pinned (torch's caching host allocator hands the blocks back when
+            # the returned numpy arrays die), device tensors kept alive until the copies have run
+            self.host = [torch.empty((n_out, H, W, c), dtype=torch.float32, pin_memory=True) for c in self.chans]
+            self.keep = []
+        else:
+            # long paths (hundreds of frames, or megapixel frames): page-locking every result would pin gigabytes that
+            # the caching host allocator never returns to the OS.  A ring of PINNED_RING staging frames instead: a
+            # frame is copied device -> slot on the copy stream, and moved slot -> pageable result when the slot comes
+            # round again (its copy event has long completed), at which point its device tensors are dropped too.
+            self.out = [np.empty((n_out, H, W, c), dtype=np.float32) for c in self.chans]
+            self.ring = [[torch.empty((H, W, c), dtype=torch.float32, pin_memory=True) for c in self.chans] for _ in range(PINNED_RING)]
+            self.pending = [None] * PINNED_RING          # (frame index, copy event, device tensors)
+
+    def _views(self, rgb, disp, acc):
+        H, W = self.H, self.W
+        return (rgb.view(H, W, 3), disp.view(H, W, 1), acc.view(H, W, 1))
+
+    def _drain(self, slot):
+        if self.pending[slot] is None:
+            return
+        k, ev, _dev_tensors = self.pending[slot]
+        ev.synchronize()
+        for o, st in zip(self.out, self.ring[slot]):
+            o[k] = st.numpy()
+        self.pending[slot] = None
+
+    def sink(self, k, rgb, disp, acc):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        if self.whole:
+            self.keep.append((rgb, disp, acc))
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(ev)
+                for dst, src in zip(self.host, self._views(rgb, disp, acc)):
+                    dst[k].copy_(src, non_blocking=True)
+            return
+        slot = k % PINNED_RING
+        self._drain(slot)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(ev)
+            for dst, src in zip(self.ring[slot], self._views(rgb, disp, acc)):
+                dst.copy_(src, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        self.pending[slot] = (k, done, (rgb, disp, acc))
+
+    def finish(self):
+        if self.whole:
+            self.copy_stream.synchronize()
+            self.keep.clear()
+            return [h.numpy() for h in self.host]
+        for slot in range(PINNED_RING):
+            self._drain(slot)
+        return self.out
 
 
 def _render_path_multi(r, render_poses, hwf, chunk, render_kwargs, centers, kp, skts, cyls, bg_imgs, cams,
@@ -208,9 +271,10 @@ def _render_path_multi(r, render_poses, hwf, chunk, render_kwargs, centers, kp, 
         raise NotImplementedError("render_path needs kp or cyls (bounding-cylinder cull)")
     if not (isinstance(H, (int, np.integer)) and isinstance(W, (int, np.integer))):
         raise ValueError("multi-device render_path needs one frame size (scalar H, W)")
-    cyls, bboxes, grids = kp_to_boxes(render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale,
-                                      centers=centers)
-    valid_idxs = [rows * w + cols for rows, cols, _, w, _, _, _ in grids]
+    cyls, bboxes, meta = frame_boxes(r, render_poses, H, W, focal, kps=kp, cylinder_params=cyls, ext_scale=ext_scale,
+                                     centers=centers)
+    cyls = torch.as_tensor(cyls).detach().float().cpu()
+    valid_idxs = BoxPixelIds(bboxes, [m[1] for m in meta])
     F = len(render_poses)
     n_pose = cyls.shape[0]
     sk = torch.as_tensor(skts).reshape(-1, 24, 4, 4)
@@ -228,9 +292,9 @@ def _render_path_multi(r, render_poses, hwf, chunk, render_kwargs, centers, kp, 
                             align_corners=False)[0].permute(1, 2, 0).reshape(int(H) * int(W), 3)
     r.set_chunk(int(chunk))
     kw = render_kwargs
-    focals = [g[4] for g in grids]
-    rgbs, disps, accs = r.render_frames(int(H), int(W), focals, [g[5] for g in grids], bboxes, sk, cy,
-                                        centers=None if centers is None else [g[6] for g in grids], cams=cm,
+    focals = [m[2] for m in meta]
+    rgbs, disps, accs = r.render_frames(int(H), int(W), focals, [m[3] for m in meta], bboxes, sk, cy,
+                                        centers=None if centers is None else [m[4] for m in meta], cams=cm,
                                         n_samples=kw.get("N_samples"), n_importance=kw.get("N_importance"),
                                         lindisp=bool(kw.get("lindisp", False)), bg=bg, base_bg=1.0 if white_bkgd else 0.0)
     return rgbs, disps, accs if ret_acc else [], valid_idxs, bboxes

@@ -60,10 +60,11 @@ class _RenderRaysFn(torch.autograd.Function):
                 t = _dev_f32(t, dev)
                 keep.append(t)
                 setattr(pd, k, t.data_ptr())
+        tape = C.c_int64(0)
         r._check(lib.pg_train_forward(r.handle, r._stream(), n, _ptr(rb), _ptr(sk), ps, _ptr(cy), cs, _ptr(cam), S, N, flags,
                                       None if pd is None else C.byref(pd), C.byref(structs[0]),
-                                      C.byref(structs[1]) if N > 0 else None, C.byref(po)))
-        ctx.caster, ctx.n_nets, ctx.nper, ctx.keep = caster, len(nets), nper, keep
+                                      C.byref(structs[1]) if N > 0 else None, C.byref(po), C.byref(tape)))
+        ctx.caster, ctx.n_nets, ctx.nper, ctx.keep, ctx.tape_id = caster, len(nets), nper, keep, tape.value
         ctx.shapes = [tuple(p.shape) for p in params]
         zero = lambda k: out[k] if k in out else torch.zeros(0, device=dev)
         outs = (out["rgb_map"], out["acc_map"], zero("rgb0"), zero("acc0"), out["disp_map"], zero("disp0"))
@@ -88,15 +89,80 @@ class _RenderRaysFn(torch.autograd.Function):
             g.zero_()
         gp = lambda g: None if g is None or g.numel() == 0 else _dev_f32(g, dev)
         a, b, c, d = gp(g_rgb), gp(g_acc), gp(g_rgb0), gp(g_acc0)
-        r._check(r.lib.pg_train_backward(r.handle, r._stream(), _ptr(a), _ptr(b), _ptr(c), _ptr(d), C.byref(structs[0]),
+        # (a forward pass in between has overwritten the handle's one tape: the library refuses the stale id)
+        r._check(r.lib.pg_train_backward(r.handle, r._stream(), ctx.tape_id, _ptr(a), _ptr(b), _ptr(c), _ptr(d), C.byref(structs[0]),
                                          C.byref(structs[1]) if ctx.n_nets > 1 else None))
         return (None, None) + tuple(grads)
 
 
+class _NetParams(torch.nn.Module):
+    """The parameters of one NeRF net under the reference's names (core/networks/nerf.py:57-88): pts_linears.{0..7},
+    alpha_linear, feature_linear, views_linears.0, rgb_linear (+ framecodes.codes, core/networks/embedding.py).  The
+    nn.Linear / nn.Embedding modules are containers only -- the arithmetic runs in the library -- but they make
+    `state_dict()` the reference checkpoint's `network_fn_state_dict`, `named_parameters()` its parameter list, and
+    `pts_linears[i].parameters()` what get_grad_vars' freeze_weights walks (raycasters.py:194-203)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], framecodes: bool, device):
+        super().__init__()
+        lin = lambda name: self._linear(sd[f"{name}.weight"], sd[f"{name}.bias"], device)
+        self.pts_linears = torch.nn.ModuleList([lin(f"pts_linears.{i}") for i in range(8)])
+        self.alpha_linear = lin("alpha_linear")
+        self.feature_linear = lin("feature_linear")
+        self.views_linears = torch.nn.ModuleList([lin("views_linears.0")])
+        self.rgb_linear = lin("rgb_linear")
+        if framecodes:
+            codes = sd["framecodes.codes.weight"]
+            self.framecodes = torch.nn.Module()
+            self.framecodes.codes = torch.nn.Embedding(codes.shape[0], codes.shape[1], device=device)
+            with torch.no_grad():
+                self.framecodes.codes.weight.copy_(codes)
+
+    @staticmethod
+    def _linear(w, b, device):
+        m = torch.nn.Linear(w.shape[1], w.shape[0], device=device)
+        with torch.no_grad():
+            m.weight.copy_(w)
+            m.bias.copy_(b)
+        return m
+
+    def tensors(self, names):
+        p = dict(self.named_parameters())
+        return [p[k] for k in names]
+
+
+class _EmbedState(torch.nn.Module):
+    """State of one CutoffEmbedder as the reference checkpoints it (core/cutoff_embedder.py:89-94): `cutoff_dist`
+    Parameter[24] (requires_grad=False, opt_cutoff off) and the `tau` buffer, with the tau schedule of
+    update_threshold (cutoff_embedder.py:176-183; the frequency schedule is off in every shipped config)."""
+
+    def __init__(self, renderer, which: int, sd: Dict[str, torch.Tensor]):
+        super().__init__()
+        self._renderer, self._which = [renderer], which          # (a list: not a sub-module)
+        self.cutoff_dist = torch.nn.Parameter(sd["cutoff_dist"].clone().float(), requires_grad=False)
+        self.register_buffer("tau", sd["tau"].clone().float().reshape(()))
+        self.init_tau = 20.0                                      # CutoffEmbedder(init_tau=20): cutoff_embedder.py:66
+
+    def get_tau(self):
+        return float(self.tau)
+
+    def set(self, tau, cutoff_dist=None):
+        if cutoff_dist is not None:
+            with torch.no_grad():
+                self.cutoff_dist.copy_(torch.as_tensor(cutoff_dist).float())
+        self.tau.fill_(float(tau))
+        self._renderer[0].set_embedder(self._which, float(tau), self.cutoff_dist.detach().cpu().numpy())
+
+    def update_threshold(self, global_step, tau_step, tau_rate, alpha_step=None, alpha_target=None):
+        self.set(min(self.init_tau * tau_rate ** (global_step / float(tau_step * 1000)), 2000.))
+
+
 class TrainableRayCaster(torch.nn.Module):
     """`HipRayCaster` with a gradient: the object to put under `render_kwargs_train['ray_caster']`
-    (core/raycasters.py:156-165).  `parameters()` are the reference's tensors (same names under `network.` /
-    `network_fine.`, nerf.py:57-88), so `get_grad_vars` + Adam (raycasters.py:186-228) work unchanged;
+    (core/raycasters.py:156-165).  It has the surface the reference's trainer touches: `get_networks()` /
+    `get_embed_fns()` (so `get_grad_vars` + Adam, raycasters.py:186-228, work unchanged), `update_embed_fns`
+    (trainer.py:265-266), `.module`, and `state_dict()` / `load_state_dict()` in the reference checkpoint layout
+    (raycasters.py:752-788: `network_fn_state_dict` with `pts_linears.0.weight`, ..., `embed_state_dict`, ...), which
+    `HipRayCaster.load_state_dict`, `load_raycaster` and the reference itself read back.
     `sync_inference_weights()` hands the current values to the fused inference kernels (validation renders)."""
 
     def __init__(self, caster: HipRayCaster):
@@ -105,13 +171,13 @@ class TrainableRayCaster(torch.nn.Module):
         self.cfg = caster.cfg
         dev = caster.renderer.device
         st = caster.renderer._state
-        names = list(NET_TENSOR_ORDER) + (["framecodes.codes.weight"] if self.cfg.framecode_ch > 0 else [])
-        self._names = names
-
-        def net(sd):
-            return torch.nn.ParameterDict({k.replace(".", "__"): torch.nn.Parameter(sd[k].to(dev).float().contiguous()) for k in names})
-        self.network = net(st["network_fn_state_dict"])
-        self.network_fine = net(st["network_fine_state_dict"]) if "network_fine_state_dict" in st else None
+        fc = self.cfg.framecode_ch > 0
+        self._names = list(NET_TENSOR_ORDER) + (["framecodes.codes.weight"] if fc else [])
+        self.network = _NetParams(st["network_fn_state_dict"], fc, dev)
+        self.network_fine = _NetParams(st["network_fine_state_dict"], fc, dev) if "network_fine_state_dict" in st else None
+        self.embed_fn = _EmbedState(caster.renderer, 0, st["embed_state_dict"])
+        self.embedbones_fn = None                       # multires_bones = 0: a parameter-free identity Embedder
+        self.embeddirs_fn = _EmbedState(caster.renderer, 1, st["embeddirs_state_dict"])
 
     @property
     def module(self):
@@ -121,15 +187,50 @@ class TrainableRayCaster(torch.nn.Module):
     def renderer(self):
         return self.caster.renderer
 
-    def _flat(self):
-        out = [self.network[k.replace(".", "__")] for k in self._names]
+    # ---- the reference RayCaster's accessors (core/raycasters.py:726-794) -----------------------------------------
+    def get_networks(self):
+        return self.network, self.network_fine
+
+    def get_embed_fns(self):
+        return self.embed_fn, self.embedbones_fn, self.embeddirs_fn
+
+    def update_embed_fns(self, global_step, args):
+        for fn in (self.embed_fn, self.embeddirs_fn):
+            fn.update_threshold(global_step, args.cutoff_step, args.cutoff_rate, getattr(args, "freq_schedule_step", None),
+                                self.cfg.multires - 1)
+
+    def state_dict(self, *args, **kwargs):
+        """The reference's checkpoint entries (raycasters.py:752-766): one state dict per sub-module."""
+        cpu = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        sd = {"network_fn_state_dict": cpu(self.network), "embed_state_dict": cpu(self.embed_fn),
+              "embedbones_state_dict": {}, "embeddirs_state_dict": cpu(self.embeddirs_fn)}
         if self.network_fine is not None:
-            out += [self.network_fine[k.replace(".", "__")] for k in self._names]
+            sd["network_fine_state_dict"] = cpu(self.network_fine)
+        return sd
+
+    def load_state_dict(self, ckpt, strict=True):
+        """Resume from a checkpoint in that layout (written by this class, by HipRayCaster.state_dict or by the
+        reference's trainer, trainer.py:496-507): parameters, embedder state and the inference kernels' weights."""
+        self.network.load_state_dict(ckpt["network_fn_state_dict"], strict=strict)
+        if self.network_fine is not None and ckpt.get("network_fine_state_dict") is not None:
+            self.network_fine.load_state_dict(ckpt["network_fine_state_dict"], strict=strict)
+        for fn, key in ((self.embed_fn, "embed_state_dict"), (self.embeddirs_fn, "embeddirs_state_dict")):
+            e = ckpt.get(key)
+            if e is not None and "tau" in e:
+                fn.set(float(e["tau"]), e.get("cutoff_dist"))
+            elif strict:
+                raise KeyError(key)
+        self.sync_inference_weights()
+
+    def _flat(self):
+        out = self.network.tensors(self._names)
+        if self.network_fine is not None:
+            out += self.network_fine.tensors(self._names)
         return out
 
     def net_state_dict(self, which: int) -> Dict[str, torch.Tensor]:
         net = self.network if which == 0 else self.network_fine
-        return {k: net[k.replace(".", "__")].detach().cpu() for k in self._names}
+        return {k: v.detach().cpu() for k, v in net.state_dict().items()}
 
     def sync_inference_weights(self):
         """Re-pack the current parameter values for the fused inference kernels (after optimiser steps)."""
@@ -148,6 +249,21 @@ class TrainableRayCaster(torch.nn.Module):
             raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
         if skts is None or cyls is None:
             raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
+        if unused:
+            self.caster._check_preproc_kwargs(unused.pop("preproc_kwargs", None))
+            if unused.pop("nerf_type", "nerf") != "nerf" or not unused.pop("use_viewdirs", True):
+                raise NotImplementedError("only nerf_type='nerf' with view directions is on the HIP path")
+            for k in ("retraw", "verbose", "ext_scale", "network_fine"):
+                unused.pop(k, None)
+            if unused:
+                raise TypeError(f"TrainableRayCaster.forward: unexpected keyword arguments {sorted(unused)}")
+        # The backward pass differentiates with respect to the networks' tensors only.  The reference's pose
+        # optimisation (popt_layer, trainer.py:496-515) backpropagates into skts / kp through the embedding: refused
+        # here rather than left without a gradient (out of scope).
+        for name, t in (("ray_batch", ray_batch), ("skts", skts), ("kp_batch", kp_batch), ("cyls", cyls), ("bones", bones)):
+            if torch.is_tensor(t) and t.requires_grad:
+                raise NotImplementedError(f"{name} requires a gradient: the HIP training step has no gradient for poses / rays "
+                                          "(pose optimisation is not on the HIP path); pass a detached tensor")
         r = self.caster.renderer
         cfg = self.cfg
         S = cfg.n_samples if N_samples is None else int(N_samples)

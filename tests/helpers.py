@@ -18,7 +18,9 @@ def load_golden(name):
 def cfg_from_golden(g) -> RenderConfig:
     return RenderConfig(n_samples=int(g["n_samples"]), n_importance=int(g["n_importance"]),
                         framecode_ch=int(g.get("framecode_ch", 0)),
-                        n_framecodes=int(g.get("n_framecodes", 0)))
+                        n_framecodes=int(g.get("n_framecodes", 0)),
+                        density_type="softplus" if int(g.get("density_softplus", 0)) else "relu",
+                        softplus_shift=float(g.get("softplus_shift", 1.0)))
 
 
 def oracle_cfg(cfg: RenderConfig, tau_v, tau_d) -> orc.OracleConfig:
@@ -27,7 +29,8 @@ def oracle_cfg(cfg: RenderConfig, tau_v, tau_d) -> orc.OracleConfig:
                             net_width=cfg.net_width, skips=tuple(cfg.skips),
                             framecode_ch=cfg.framecode_ch, cutoff_dist=cfg.cutoff_dist,
                             tau_v=float(tau_v), tau_d=float(tau_d),
-                            density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps)
+                            density_scale=cfg.density_scale, rgb_eps=cfg.rgb_eps,
+                            density_type=cfg.density_type, softplus_shift=cfg.softplus_shift)
 
 
 def torch_weights(w):
