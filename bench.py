@@ -207,6 +207,9 @@ def host_to_host(caster, cfg, dev, H, W, frames=4, all_hit=False):
     dt = (time.perf_counter() - t0) / reps
     return {"valid_rays_per_s": n_valid / dt, "pixels_per_s": frames * H * W / dt, "ms_per_frame": dt / frames * 1e3,
             "frames": frames, "valid_rays": n_valid,
+            # share of the frame inside the boxes: valid_rays_per_s / box_share_of_frame is the rate a whole frame of
+            # such rays would show (what `value` counts: all H*W rays)
+            "box_share_of_frame": n_valid / float(frames * H * W),
             "what": f"render_path: {frames} poses + cameras on host -> float32 rgb/disp/acc frames {H}x{W} on host, "
                     + ("all-hit cylinder of the headline workload (radius 2.5; rays counted = rays inside the box = the frame "
                        "without its last row and column), chunk 4096, " if all_hit else
@@ -305,12 +308,15 @@ def strong_workload(caster, cfg, H, W, frames, group=None):
     c2ws, focals = syn.make_camera(frames, H, W)
     kps, skts, c2ws = torch.tensor(kps), torch.tensor(skts), torch.tensor(c2ws)
     kw = {"ray_caster": caster, "N_importance": cfg.n_importance, "N_samples": cfg.n_samples, "lindisp": False}
-    state = {}
+    state = {"host_pre_launch_ms": []}
 
     def step():
+        st = {}
         out = render_frames_distributed(c2ws, (H, W, focals), cfg.chunk, kw, group=group, kp=kps, skts=skts,
-                                        white_bkgd=True, ext_scale=cfg.ext_scale)
-        state["valid"] = sum(len(v) for v in out[3])
+                                        white_bkgd=True, ext_scale=cfg.ext_scale, stats=st)
+        state["valid"] = sum(out[3].counts()) if hasattr(out[3], "counts") else sum(len(v) for v in out[3])
+        state["host_pre_launch_ms"].append(st.get("host_pre_launch_ms", 0.0))
+        state["host_ms"] = st.get("host_ms", 0.0)
         return out
     return step, state
 
@@ -413,20 +419,34 @@ def main():
     if not strong and not a.no_strong:
         strong_step()
         sync()
-        reps = 2
+        reps = 3
+        strong_state["host_pre_launch_ms"].clear()
         t1 = time.perf_counter()
         for _ in range(reps):
             strong_step()
         sync()
         sdt = max_over_ranks(time.perf_counter() - t1) / reps
+        pre = sorted(strong_state["host_pre_launch_ms"])
+        host_serial = max_over_ranks(pre[len(pre) // 2] if pre else 0.0)
         from posegen_amd.dist import plan_tasks
         side = {"scaling": "strong", "frames_per_step": a.frames, "valid_rays_per_step": strong_state["valid"],
                 "rays_per_s": strong_state["valid"] / sdt, "ms_per_step": sdt * 1e3, "ms_per_frame": sdt * 1e3 / a.frames,
                 "n_gpus": world,
+                # host work of a step that no GPU overlaps (call entry -> first render launch: device boxes with their
+                # 16-byte-per-frame copy back, the plan, the pose upload): what every rank repeats, i.e. the serial
+                # term of the 8-GPU bound T1 / (T1 / 8 + host) of DESIGN.md 4; median over the steps, max over ranks
+                "host_serial_ms_per_step": host_serial, "host_enqueue_ms_per_step": strong_state.get("host_ms", 0.0),
                 "what": f"dist.render_frames_distributed: {a.frames} poses at {H}x{W}, reference bounding-cylinder cull, "
                         f"nanmean groups of {cfg.chunk} rays planned over {world} rank(s), one all-gather of the packed maps "
                         "inside the timed region, frames composed on every rank (device resident); rays counted = rays "
                         "inside the boxes, whole job"}
+
+    frames_sha = None
+    if strong and rank == 0 and out is not None and out[0] is not None:
+        # checksum of the last step's assembled frames: a multi-GPU run must reproduce the single-device bytes
+        # (groups stay whole) -- tests/test_gpu_configs.py compares the two
+        import hashlib
+        frames_sha = hashlib.sha256(torch.cat([out[0], out[1], out[2]], -1).float().cpu().numpy().tobytes()).hexdigest()
 
     if rank != 0:
         if world > 1:
@@ -472,6 +492,8 @@ def main():
                                                "frac_incl_records": k_pts * flops_pt / ((k_ms + aux_ms) * 1e-3) / 1e12 / peak}
     if side is not None:
         result["strong_scaling"] = side
+    if frames_sha is not None:
+        result["frames_sha256"] = frames_sha
     if a.dry_run:
         print(json.dumps(result))
         if world > 1:
@@ -521,12 +543,16 @@ def main():
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the
     # profiler on itself, so the committed measurement of the same build is attached.
     alg_bytes = 20 * k_pts / max(launches, 1)       # z in 4 B/point + raw out 16 B/point
-    for tname in (f"r3_{a.prec}_traffic.json", f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
+    for tname in (f"r4_{a.prec}_traffic.json", f"r3_{a.prec}_traffic.json", f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if H == 512 and os.path.exists(tpath) and (a.prec == "bf16" or not tname.startswith("r1_")):
             tj = json.load(open(tpath))
             result["roofline"]["traffic"] = tj["hbm_bytes"]
             result["roofline"]["traffic_unit"] = f"bytes per launch (PMC, profiles/{tname})"
+            # NOT measured by this run: the rocprofv3 --pmc passes of the build named here, taken on the builder's box
+            result["roofline"]["traffic_from"] = {"file": f"profiles/{tname}", "commit": tj.get("commit", "unrecorded (round of the file name)"),
+                                                  "box": tj.get("box", "a one-GPU MI355X box of the builder's pool"),
+                                                  "note": "attached from the committed profile of that build, not a measurement of this run"}
             # what ONE eval launch has to move given the kernel split: z in 4 B/point + raw out 16 B/point
             result["roofline"]["intermediate_bytes_per_launch"] = tj.get("algorithmic_bytes", alg_bytes)
             # against SURVEY 8(d)'s figure for the PATH (64 B/ray): a frame is 2 eval + 2 composite + 1 sampling
@@ -564,12 +590,35 @@ def main():
                 got = r.render_rays(rb[sel.to(dev)], skts, cyl)
                 m["max_abs_rgb_vs_oracle"] = float((got["rgb_map"].cpu() - ref["rgb_map"]).abs().max())
                 m["max_abs_acc_vs_oracle"] = float((got["acc_map"].cpu() - ref["acc_map"]).abs().max())
+                solid_m = ref["acc_map"] > 1e-3
+                m["max_abs_disp_vs_oracle"] = float((got["disp_map"].cpu() - ref["disp_map"])[solid_m].abs().max()) if solid_m.any() else 0.0
                 mse_m = float(((got["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean())
                 m["rgb_mse_vs_oracle"] = mse_m
                 m["rgb_psnr_db_vs_oracle"] = -10 * np.log10(max(mse_m, 1e-30))
             modes[name] = m
         r.set_precision(a.prec)
         result["modes"] = modes
+        # north_star asks for "output within 1e-4 of reference" AND ">= 50 % MFMA roofline": the fastest mode whose
+        # max-abs error of rgb, acc and disp (solid rays) against the pinned oracle is <= 1e-4 on the parity sample,
+        # next to the bf16 headline (BASELINE config 2 names "bf16 MLP"; bf16 itself is ~2e-3 from the reference)
+        if sel is not None:
+            cands = {a.prec: {"rays_per_s": rays_s, "frac": result["roofline"]["frac"],
+                              "max_abs_rgb_vs_oracle": result["parity"]["max_abs"]["rgb_map"],
+                              "max_abs_acc_vs_oracle": result["parity"]["max_abs"]["acc_map"],
+                              "max_abs_disp_vs_oracle": result["parity"]["max_abs"]["disp_map(acc>1e-3)"]}}
+            cands.update(modes)
+            ok = {k: v for k, v in cands.items() if max(v["max_abs_rgb_vs_oracle"], v["max_abs_acc_vs_oracle"],
+                                                         v["max_abs_disp_vs_oracle"]) <= 1e-4}
+            if ok:
+                best = max(ok, key=lambda k: ok[k]["rays_per_s"])
+                result["north_star_mode"] = {
+                    "mode": best, "rays_per_s": ok[best]["rays_per_s"], "frac": ok[best]["frac"], "tolerance": 1e-4,
+                    "max_abs": {k: ok[best][f"max_abs_{k}_vs_oracle"] for k in ("rgb", "acc", "disp")},
+                    "rays_in_sample": int(len(sel)),
+                    "what": "fastest precision mode within 1e-4 (max-abs rgb / acc / disp of solid rays) of the fp32 oracle on "
+                            "the parity sample; frac = fused kernel on algorithmic FLOPs over the 2.5 PFLOP/s dense 16-bit peak"}
+            else:
+                result["north_star_mode"] = None
 
     if world == 1 and not a.no_extras:
         result["host_to_host"] = host_to_host(caster, cfg, dev, H, W)

@@ -118,14 +118,17 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 
 // ---- fp32 GEMM: C[M,N] (op)= A[M,K] B[K,N] with element strides, 64 x 64 x 16 tiles on v_mfma_f32_32x32x2_f32 ------
 // A(m,k) = A[m sam + k sak], B(k,n) = B[k sbk + n sbn]; the template flags say which index is contiguous (coalesced
-// tile loads).  gridDim.z > 1 splits K and adds the partial tiles into C with float atomics (C zeroed by the caller).
+// tile loads).  gridDim.z > 1 splits K: the partial tiles go to a scratch array and are summed in slice order.
 constexpr int GB = 64, GK = 16;
 enum { GEMM_ACC = 1, GEMM_RELU = 2 };
 
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
                                                     const float* __restrict__ B, long long sbk, long long sbn,
-                                                    float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags) {
+                                                    float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                    float* __restrict__ part) {
+    // gridDim.z > 1: K is split; slice z writes its tile to part[z][M][N] and reduce_parts_kernel adds the slices in
+    // order (bitwise repeatable, unlike float atomics)
     __shared__ float As[GK][GB + 4], Bs[GK][GB + 4];
     const int t = threadIdx.x;
     // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the tile: v_mfma_f32_32x32x2_f32, A lane (row li, k kh), B lane
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
             if (m >= M) continue;
             float* c = C + (long long)m * ldc + n;
             float v = acc[r];
-            if (nz > 1) { atomicAdd(c, v); continue; }
+            if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
             if (flags & GEMM_ACC) v += *c;
             if (bias) v += bias[n];
             if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
@@ -228,9 +231,12 @@ template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
                                                        const float* __restrict__ B, long long sbk, long long sbn,
                                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
-                                                       const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum) {
+                                                       const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
+                                                       float* __restrict__ part, float* __restrict__ rs_part) {
     // mask: C(m,n) is zeroed where mask[m ldm + n] <= 0 (the ReLU backward of the layer that consumes C, fused);
-    // rowsum (A m-contiguous only): rowsum[m] += sum_k A(m,k) (the bias gradient beside a weight gradient)
+    // rowsum (A m-contiguous only): sum_k A(m,k) (the bias gradient beside a weight gradient): block (x, z) writes the
+    // share of its k-steps to rs_part[z * gridDim.x + x][M]; reduce_parts_kernel adds the shares in order.
+    // gridDim.z > 1: slice z's tile goes to part[z][M][N] (summed in slice order by reduce_parts_kernel)
     __shared__ __attribute__((aligned(16))) float As[GK][TB + 4], Bs[GK][TB + 4];
     float rs = 0.0f;
     const int t = threadIdx.x;
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
                 if (m >= M) continue;
                 float* c = C + (long long)m * ldc + n;
                 float v = acc[i][j][r];
-                if (nz > 1) { atomicAdd(c, v); continue; }
+                if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
                 if (flags & GEMM_ACC) v += *c;
                 v += bv;
                 if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
@@ -292,7 +298,17 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
                 *c = v;
             }
     }
-    if (!A_KCONT && rowsum && t < TB && m0 + t < M) atomicAdd(rowsum + m0 + t, rs);
+    if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
+}
+
+// out[i (row-major M x N with leading dimension ldo)] = sum over the nz slices of part[z][M][N], in slice order
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nz, int M, int N,
+                                                          float* __restrict__ out, long long ldo) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x, MN = (long long)M * N;
+    if (i >= MN) return;
+    float s = 0.0f;
+    for (int z = 0; z < nz; ++z) s += part[z * MN + i];
+    out[(i / N) * ldo + (i % N)] = s;
 }
 
 // dH <- dH where H > 0 else 0 (ReLU backward on the stored post-activation)
@@ -301,32 +317,41 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, c
         if (!(h[i] > 0.0f)) d[i] = 0.0f;
 }
 
-// out[n] += sum over rows of d[row * ld + n] (bias gradients); one block per 256 rows, float atomics
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ out) {
+// part[block][n] = sum over the block's 256 rows of d[row * ld + n] (bias gradients; reduce_parts_kernel adds the
+// blocks in order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part) {
     const long long r0 = blockIdx.x * 256ll, r1 = min(rows, r0 + 256);
     for (int n = threadIdx.x; n < N; n += 256) {
         float s = 0.0f;
         for (long long r = r0; r < r1; ++r) s += d[r * ld + n];
-        atomicAdd(out + n, s);
+        part[(long long)blockIdx.x * N + n] = s;
     }
 }
 
-// gradient of the frame codes: dcodes[index of the point's ray] += dxc[point] (embedding.py:19-36; the mean code of a
-// negative index spreads its gradient evenly, like codes.mean(0))
-__global__ __launch_bounds__(256) void code_scatter_kernel(const float* __restrict__ dxc, long long n_points, int S,
-                                                           const float* __restrict__ cams, int n_codes, float* __restrict__ dcodes) {
+// gradient of the frame codes (embedding.py:19-36), in two ordered steps: per ray the sum of dxc over its S points,
+// then per (code, channel) the sum over the rays that index it, in ray order; the mean code of a negative index
+// spreads its gradient evenly over all rows, like codes.mean(0)
+__global__ __launch_bounds__(256) void code_ray_sum_kernel(const float* __restrict__ dxc, long long n_rays, int S, float* __restrict__ ray_g) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
-    if (i >= n_points * FC_CH) return;
-    const long long pt = i / FC_CH;
-    const int k = (int)(i - pt * FC_CH);
-    const float cam = cams ? cams[pt / S] : -1.0f;
-    const float g = dxc[pt * FC_CH + k];
-    if (cam < 0.0f) {
-        const float gm = g / (float)n_codes;
-        for (int c = 0; c < n_codes; ++c) atomicAdd(dcodes + c * FC_CH + k, gm);
-    } else {
-        atomicAdd(dcodes + min((int)cam, n_codes - 1) * FC_CH + k, g);
+    if (i >= n_rays * FC_CH) return;
+    const long long ray = i / FC_CH;
+    const int k = (int)(i - ray * FC_CH);
+    float s = 0.0f;
+    for (int p = 0; p < S; ++p) s += dxc[(ray * S + p) * FC_CH + k];
+    ray_g[i] = s;
+}
+__global__ __launch_bounds__(64) void code_gather_kernel(const float* __restrict__ ray_g, long long n_rays, const float* __restrict__ cams,
+                                                        int n_codes, float* __restrict__ dcodes) {
+    const int c = blockIdx.x, k = threadIdx.x;
+    if (k >= FC_CH) return;
+    float own = 0.0f, mean = 0.0f;
+    for (long long r = 0; r < n_rays; ++r) {
+        const float cam = cams ? cams[r] : -1.0f;
+        const float g = ray_g[r * FC_CH + k];
+        if (cam < 0.0f) mean += g / (float)n_codes;
+        else if (min((int)cam, n_codes - 1) == c) own += g;
     }
+    dcodes[c * FC_CH + k] = own + mean;
 }
 
 // ---- backward of raw2outputs (core/networks/nerf.py:150-205), one thread per ray ---------------------------------
@@ -409,10 +434,14 @@ struct Tape {
     int S = 0, N = 0, fc = 0;
     float *rays = nullptr, *cams = nullptr;
     float *tmpA = nullptr, *tmpB = nullptr, *dG = nullptr, *dC = nullptr, *d_raw = nullptr;
+    float *part = nullptr, *rs_part = nullptr, *ray_g = nullptr;      // split-K slices, row / column sum shares, per-ray code gradients
     Pass pass[2];
     pg_net_params params[2];
     bool has_fine = false;
 };
+
+constexpr size_t PART_FLOATS = 20u << 20;        // split-K scratch: slices x M x N of the largest weight gradient (80 MB)
+constexpr size_t RS_FLOATS = 1u << 20;
 
 inline Tape* tape_of(pg_handle* h) {
     if (!h->train) h->train = new Tape();
@@ -425,40 +454,58 @@ inline Tape* tape_of(pg_handle* h) {
         if (e_ != hipSuccess) return pg_fail(h, PG_EHIP, "%s launch failed: %s", what, hipGetErrorString(e_)); \
     } while (0)
 
-// C[M,N] = A B (+ bias, relu, accumulate); ksplit > 1: atomic accumulation into C
+// C[M,N] = A B (+ bias, relu, accumulate); ksplit > 1: K in slices, summed into C in slice order (C is overwritten)
 int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const float* A, long long sam, long long sak,
          const float* B, long long sbk, long long sbn, float* C, long long ldc, const float* bias, int flags, int ksplit = 1,
          const float* mask = nullptr, long long ldm = 0, float* rowsum = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
+    Tape& t = *tape_of(h);
+    if (ksplit > 1) {
+        const long long fit = (long long)(PART_FLOATS / ((size_t)M * N));
+        if (fit < 2) return pg_fail(h, PG_EINVAL, "split-K scratch too small for a %d x %d result", M, N);
+        if (ksplit > fit) ksplit = (int)fit;
+        if (!t.part) return pg_fail(h, PG_ESTATE, "split-K GEMM without a tape");
+    }
+    auto reduce = [&](const float* part, int nz, int rows, int cols, float* out, long long ldo) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)(((long long)rows * cols + 255) / 256)), dim3(256), 0, s, part, nz, rows, cols, out, ldo);
+    };
     auto al4 = [](const void* p, long long a, long long b) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && a % 4 == 0 && b % 4 == 0; };
     // (the strides that are not 1 must keep 16-byte alignment of every row / k start; M, N, K multiples of 4)
     const bool big = M >= 64 && N >= 64 && M % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
                      al4(A, a_kcont ? sam : sak, 4) && al4(B, b_kcont ? sbn : sbk, 4);
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
-        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
-        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
-        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum);
+        if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
+        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
+        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
+        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
         PG_LAUNCH_CHECK(h, "sgemm128");
+        if (ksplit > 1) { reduce(t.part, ksplit, M, N, C, ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
+        if (rowsum && !a_kcont) { reduce(t.rs_part, ksplit * (int)g.x, M, 1, rowsum, 1); PG_LAUNCH_CHECK(h, "row-sum reduction"); }
         return PG_OK;
     }
     // small or unaligned shapes: the 64-tile kernel, then the mask / the row sums as kernels of their own
     if (mask && (ldc != N || ldm != N)) return pg_fail(h, PG_EINVAL, "ReLU mask behind a strided GEMM result is not supported");
     if (rowsum && a_kcont) return pg_fail(h, PG_EINVAL, "row sums need the m-contiguous A operand");
     const dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, ksplit);
-    if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
-    else if (a_kcont) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
-    else if (!b_kcont) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags);
+    if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
+    else if (a_kcont) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
+    else if (!b_kcont) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
     else return pg_fail(h, PG_EINVAL, "unsupported GEMM operand layout");
     PG_LAUNCH_CHECK(h, "sgemm");
+    if (ksplit > 1) { reduce(t.part, ksplit, M, N, C, ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
     if (mask) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)M * N + 255) / 256, 8192);
         hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, C, mask, (long long)M * N);
         PG_LAUNCH_CHECK(h, "relu_mask");
     }
     if (rowsum) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, A, (long long)K, M, sak, rowsum);
+        const unsigned blocks = (unsigned)((K + 255) / 256);
+        if ((size_t)blocks * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
+        hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, (long long)K, M, sak, t.rs_part);
         PG_LAUNCH_CHECK(h, "colsum");
+        reduce(t.rs_part, (int)blocks, 1, M, rowsum, M);
+        PG_LAUNCH_CHECK(h, "column-sum reduction");
     }
     return PG_OK;
 }
@@ -473,7 +520,7 @@ int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
                  float* dX, long long ldx, int flags, const float* relu_of = nullptr) {
     return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx);
 }
-// dW[out,in] += dY[P,out]^T X[P,in] (split-K over the points, atomics: dW zeroed by the caller)
+// dW[out,in] = dY[P,out]^T X[P,in] (split-K over the points, slices summed in order)
 int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* X, long long ldx,
                  float* dW, long long ldw, float* db = nullptr) {      // db[out] += column sums of dY (the bias gradient, fused)
     const int tb = (out >= 64 && in >= 64) ? TB : GB;            // the tile gemm() will pick
@@ -482,8 +529,13 @@ int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
     return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2), nullptr, 0, db);
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d, rows, N, ld, out);
+    Tape& t = *tape_of(h);
+    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    if ((size_t)blocks * N > RS_FLOATS) return pg_fail(h, PG_EINVAL, "column-sum scratch too small");
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, d, rows, N, ld, t.rs_part);
     PG_LAUNCH_CHECK(h, "colsum");
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, t.rs_part, (int)blocks, 1, N, out, (long long)N);
+    PG_LAUNCH_CHECK(h, "column-sum reduction");
     return PG_OK;
 }
 int relu_mask(pg_handle* h, hipStream_t s, float* d, const float* hh, long long count) {
@@ -541,8 +593,10 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, const Pass& p, const pg_n
     if (fc && g.codes) {
         PG_HIP(h, hipMemsetAsync(g.codes, 0, (size_t)w.n_codes * FC_CH * sizeof(float), s));
         PG_TRY(linear_bwd_x(h, s, P, VW, FC_CH, dG, VW, w.w[20] + W + CH_D, vcols, t.dC, FC_CH, 0));
-        hipLaunchKernelGGL(code_scatter_kernel, dim3((unsigned)((P * FC_CH + 255) / 256)), dim3(256), 0, s, t.dC, P, p.S, t.cams, w.n_codes, g.codes);
-        PG_LAUNCH_CHECK(h, "code_scatter");
+        hipLaunchKernelGGL(code_ray_sum_kernel, dim3((unsigned)((t.n * FC_CH + 255) / 256)), dim3(256), 0, s, t.dC, (long long)t.n, p.S, t.ray_g);
+        PG_LAUNCH_CHECK(h, "code_ray_sum");
+        hipLaunchKernelGGL(code_gather_kernel, dim3((unsigned)w.n_codes), dim3(64), 0, s, t.ray_g, (long long)t.n, t.cams, w.n_codes, g.codes);
+        PG_LAUNCH_CHECK(h, "code_gather");
     }
     // feature_linear and alpha_linear on the trunk output
     const float* h7 = p.H[DEPTH - 1];
@@ -618,6 +672,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     };
     need += pass_bytes(Pc) + (N > 0 ? pass_bytes(Pf) : 0);
     need += 2 * al((size_t)Pm * W * 4) + al((size_t)Pm * VW * 4) + al((size_t)Pm * FC_CH * 4) + al((size_t)Pm * 16);
+    need += al(PART_FLOATS * 4) + al(RS_FLOATS * 4) + al((size_t)n * FC_CH * 4);
     if (need > t.bytes) {
         if (t.buf) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(t.buf)); t.buf = nullptr; t.bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.buf), need);
@@ -648,6 +703,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     }
     t.tmpA = take((size_t)Pm * W * 4); t.tmpB = take((size_t)Pm * W * 4);
     t.dG = take((size_t)Pm * VW * 4); t.dC = take((size_t)Pm * FC_CH * 4); t.d_raw = take((size_t)Pm * 16);
+    t.part = take(PART_FLOATS * 4); t.rs_part = take(RS_FLOATS * 4); t.ray_g = take((size_t)n * FC_CH * 4);
     t.params[0] = *coarse;
     if (N > 0) t.params[1] = *fine;
     PG_HIP(h, hipMemcpyAsync(t.rays, ray_batch, (size_t)n * 44, hipMemcpyDeviceToDevice, s));

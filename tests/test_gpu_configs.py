@@ -253,3 +253,31 @@ def test_per_ray_poses_equal_the_per_pose_calls(prec):
         w = which if both[k].dim() == 1 else which[:, None]
         assert torch.equal(both[k], torch.where(w, one_b[k], one_a[k])), k
     assert float((one_a["rgb_map"] - one_b["rgb_map"]).abs().max()) > 1e-3        # the poses do differ
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (self-arming: runs wherever the box has them)")
+def test_two_process_rccl_strong_scaling_equals_the_single_device_frames():
+    """BASELINE configs 3 / 5 on real hardware as soon as a box has >= 2 GPUs: `bench.py --gpus 2 --scaling strong`
+    as a CHILD process (one process per GPU under torch.distributed.run, backend nccl = RCCL; a process that has
+    touched the GPU must not exec) renders 5 culled 128 x 128 frames shared by the two ranks -- frames cut on
+    nanmean-group boundaries, one all-gather, compose on every rank -- and reports the sha256 of the assembled frames:
+    it must be the single-device render's, byte for byte."""
+    import hashlib
+    import json
+    from bench import strong_workload
+    from posegen_amd.raycaster import HipRayCaster
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--scaling", "strong", "--frames", "5", "--res", "128",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-modes", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    cfg = surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=DEV, precision="bf16")
+    c.renderer.set_chunk(cfg.chunk)
+    step, _ = strong_workload(c, cfg, 128, 128, 5)
+    o = step()
+    sha = hashlib.sha256(torch.cat([o[0], o[1], o[2]], -1).float().cpu().numpy().tobytes()).hexdigest()
+    assert line["frames_sha256"] == sha, "two ranks reproduce the single-device frames bitwise"
+    c.renderer.close()

@@ -42,7 +42,7 @@ def casters():
     cache = {}
 
     def get(cfg, seed, prec):
-        key = (cfg.n_samples, cfg.n_importance, cfg.framecode_ch, seed)
+        key = (cfg.n_samples, cfg.n_importance, cfg.framecode_ch, seed, cfg.density_type, cfg.softplus_shift)
         if key not in cache:
             wc, wf, tv, td = model_for(cfg, seed)
             cache[key] = HipRayCaster.from_weights(cfg, wc, wf, tv, td, device=DEV, precision=prec)
@@ -220,7 +220,7 @@ def test_stage_composite_fine_pass(casters):
 
 
 # ------------------------------------------------------------------ whole render_rays
-RAY_CASES = ["rays_surreal", "rays_allhit", "rays_coarse32", "rays_cfg1", "rays_h36m"]
+RAY_CASES = ["rays_surreal", "rays_allhit", "rays_coarse32", "rays_cfg1", "rays_h36m", "rays_softplus"]
 
 
 @pytest.mark.parametrize("name", RAY_CASES)

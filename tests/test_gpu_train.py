@@ -29,12 +29,16 @@ def _trainable(g):
     return cfg, TrainableRayCaster(c)
 
 
-@pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m"])
+@pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m", "train_grads_softplus", "train_grads_raw"])
 def test_training_step_gradients_match_the_reference_autograd(name):
     """One training step of the reference on the HIP path: same draws (pytest=True), same loss; the loss, the four
     maps it reads and the gradient of every parameter tensor of both nets (24 each, + the frame codes) within 1e-4 of
-    the tensor's largest entry / of its norm."""
+    the tensor's largest entry / of its norm.  `train_grads_softplus`: --density_type softplus (its derivative in the
+    composite backward).  `train_grads_raw` is the UN-FILTERED h36m batch (a ReLU pre-activation within rounding of
+    zero: the reference's own gradient moves by `grad_sensitivity` = 2.5e-4 under 1e-7 weight noise): its bound is
+    4 x that stored sensitivity instead of 1e-4."""
     g = load_golden(name)
+    tol = max(1e-4, 4.0 * float(g["grad_sensitivity"])) if name == "train_grads_raw" else 1e-4
     cfg, m = _trainable(g)
     m.train()
     cams = torch.tensor(g["cams"]) if "cams" in g else None
@@ -47,16 +51,15 @@ def test_training_step_gradients_match_the_reference_autograd(name):
     loss.backward()
     n_checked = 0
     for tag, net in (("coarse", m.network), ("fine", m.network_fine)):
-        for key, p in net.items():
-            k = key.replace("__", ".")
+        for k, p in net.named_parameters():          # the reference's parameter names (nerf.py:57-88)
             ref_vals, ref_norm = g[f"gval_{tag}_{k}"], float(g[f"gnorm_{tag}_{k}"])
             assert p.grad is not None, (tag, k)
             got = p.grad.detach().cpu().numpy().reshape(-1)
             scale = max(float(np.abs(ref_vals).max()), ref_norm / np.sqrt(got.size), 1e-12)
             err = float(np.abs(got[grad_sample_index(got.size)] - ref_vals).max())
             nerr = abs(float(np.linalg.norm(got.astype(np.float64))) - ref_norm)
-            assert err <= 1e-4 * scale + 1e-9, (tag, k, err, scale)
-            assert nerr <= 1e-4 * ref_norm + 1e-9, (tag, k, nerr, ref_norm)
+            assert err <= tol * scale + 1e-9, (tag, k, err, scale)
+            assert nerr <= tol * ref_norm + 1e-9, (tag, k, nerr, ref_norm)
             n_checked += 1
     assert n_checked == (50 if cfg.framecode_ch else 48)
     m.renderer.close()
@@ -88,8 +91,7 @@ def test_training_gradients_of_an_odd_batch_match_the_oracle_autograd():
     out = m(rb, N_samples=33, skts=sk, cyls=cy, N_importance=7, draws={k: v.to(DEV) for k, v in draws.items()})
     _loss_of(out, target.to(DEV)).backward()
     for tag, net, refw in (("coarse", m.network, twc), ("fine", m.network_fine, twf)):
-        for key, p in net.items():
-            k = key.replace("__", ".")
+        for k, p in net.named_parameters():
             r = refw[k].grad.numpy().reshape(-1)
             got = p.grad.detach().cpu().numpy().reshape(-1)
             scale = max(float(np.abs(r).max()), float(np.linalg.norm(r)) / np.sqrt(r.size), 1e-12)
@@ -133,6 +135,96 @@ def test_backward_without_a_forward_is_refused():
     from posegen_amd.raycaster import HipRenderer
     r = HipRenderer(surreal_config(), DEV)
     gr = _ffi.PgNetGrads()
-    rc = r.lib.pg_train_backward(r.handle, None, None, None, None, None, C.byref(gr), C.byref(gr))
+    rc = r.lib.pg_train_backward(r.handle, None, 1, None, None, None, None, C.byref(gr), C.byref(gr))
     assert rc == _ffi.PG_ESTATE and b"pg_train_forward" in r.lib.pg_last_error(r.handle)
     r.close()
+
+
+def test_a_second_forward_makes_the_first_tape_stale():
+    """the handle holds ONE tape.  Two training-mode forwards, then backward through the FIRST: refused
+    (PG_ESTATE, 'overwritten') instead of differentiating the second call's activations; backward through the second
+    still works, and its gradients equal those of a lone forward + backward (bitwise: the reductions are ordered)."""
+    from posegen_amd._ffi import PgError, PG_ESTATE
+    g = load_golden("train_grads")
+    cfg, m = _trainable(g)
+    m.train()
+    rb, sk, cy = torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    target = torch.tensor(g["target"], device=DEV)
+    call = lambda rays: m(rays, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance, draws=None)
+    first = _loss_of(call(rb[:24]), target[:24])
+    second = _loss_of(call(rb[8:40]), target[8:40])
+    with pytest.raises(PgError) as ei:
+        first.backward()
+    assert ei.value.code == PG_ESTATE and "overwritten" in str(ei.value)
+    m.zero_grad()
+    second.backward()
+    got = [p.grad.clone() for p in m.network.parameters() if p.grad is not None]
+    m.zero_grad()
+    _loss_of(call(rb[8:40]), target[8:40]).backward()
+    again = [p.grad for p in m.network.parameters() if p.grad is not None]
+    assert len(got) == 24 and all(torch.equal(a, b) for a, b in zip(got, again)), "gradients are bitwise repeatable"
+    m.renderer.close()
+
+
+def test_checkpoint_round_trip_in_the_reference_layout(tmp_path):
+    """TrainableRayCaster.state_dict() is the reference checkpoint (raycasters.py:752-766:
+    network_fn_state_dict with pts_linears.0.weight ..., embed_state_dict with cutoff_dist / tau ...): saved with
+    torch.save like Trainer.save_nerf (trainer.py:496-507), it is read back by HipRayCaster.load_state_dict /
+    load_raycaster and by TrainableRayCaster.load_state_dict, and get_grad_vars' accessors exist."""
+    from posegen_amd.raycaster import NET_TENSOR_ORDER, HipRayCaster, load_raycaster
+    g = load_golden("train_grads")
+    cfg, m = _trainable(g)
+    m.train()
+    net, fine = m.get_networks()
+    embed, embedbones, embeddirs = m.get_embed_fns()
+    assert embedbones is None and len(list(net.pts_linears[0].parameters())) == 2
+    assert [k for k, _ in net.named_parameters()] == list(NET_TENSOR_ORDER)
+    assert not any(p.requires_grad for p in embed.parameters())       # cutoff_dist: requires_grad=False (opt_cutoff off)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-3)
+    rb, sk, cy = torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    out = m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+    _loss_of(out, torch.tensor(g["target"], device=DEV)).backward()
+    opt.step()                                                         # weights now differ from the initial ones
+    import argparse
+    m.update_embed_fns(150000, argparse.Namespace(cutoff_step=250, cutoff_rate=10.))      # tau: 20 * 10^(150/250) = 79.6
+    assert abs(embed.get_tau() - 79.62) < 0.01
+    sd = m.state_dict()
+    assert set(sd) == {"network_fn_state_dict", "network_fine_state_dict", "embed_state_dict", "embedbones_state_dict", "embeddirs_state_dict"}
+    assert set(sd["network_fn_state_dict"]) == set(NET_TENSOR_ORDER) and set(sd["embed_state_dict"]) == {"cutoff_dist", "tau"}
+    path = tmp_path / "000001.tar"
+    torch.save({"global_step": 1, **sd}, path)
+    m.sync_inference_weights()
+    m.eval()
+    with torch.no_grad():
+        want = m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+    # (1) a fresh inference caster from the file
+    kw = load_raycaster(str(path), cfg, device=DEV, precision="fp32")
+    got = kw["ray_caster"](rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+    for k in ("rgb_map", "acc_map", "disp_map"):
+        assert torch.equal(got[k], want[k]), k
+    # (2) a fresh trainable caster resumes from it
+    cfg2, m2 = _trainable(g)
+    m2.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    for (ka, a), (kb, b) in zip(m.network_fine.named_parameters(), m2.network_fine.named_parameters()):
+        assert ka == kb and torch.equal(a, b)
+    assert m2.embeddirs_fn.get_tau() == m.embeddirs_fn.get_tau()
+    m2.eval()
+    with torch.no_grad():
+        got2 = m2(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+    assert torch.equal(got2["rgb_map"], want["rgb_map"])
+    for c in (m, m2, kw["ray_caster"]):
+        c.renderer.close()
+
+
+def test_inputs_that_want_a_gradient_are_refused():
+    """poses / rays get no gradient on the HIP path (pose optimisation, trainer.py:496-515, is out of
+    scope): a tensor that requires one is refused instead of silently left without."""
+    g = load_golden("train_grads")
+    cfg, m = _trainable(g)
+    m.train()
+    rb, sk, cy = torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    with pytest.raises(NotImplementedError, match="skts requires a gradient"):
+        m(rb, N_samples=cfg.n_samples, skts=sk.clone().requires_grad_(True), cyls=cy, N_importance=cfg.n_importance)
+    with pytest.raises(TypeError):
+        m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance, no_such_argument=1)
+    m.renderer.close()

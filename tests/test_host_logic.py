@@ -381,3 +381,61 @@ def test_checkpoint_discovery_follows_the_reference(tmp_path):
     assert find_checkpoint(str(tmp_path / "logs"), "exp", ft_path="None") == str(d / "150000.tar")
     assert find_checkpoint(str(tmp_path / "logs"), "exp", ft_path="/x/y.tar") == "/x/y.tar"
     assert find_checkpoint(str(tmp_path / "logs"), "exp", no_reload=True) is None
+
+
+def test_unsupported_preproc_kwargs_are_refused_not_ignored():
+    """a caller configured for something the kernels do not compute (another encoder, another
+    density function or scale) gets an exception, not a ReLU / RelDist render.  Host logic only (no GPU)."""
+    import pytest
+    import torch.nn.functional as F
+    from posegen_amd import surreal_config
+    from posegen_amd.raycaster import HipRayCaster, _density_act
+
+    class RelDistEncoder: pass
+    class VecNormEncoder: pass
+    class WorldToLocalEncoder: pass
+    class RayAngEncoder: pass
+
+    def caster(**kw):
+        c = HipRayCaster.__new__(HipRayCaster)          # the check needs the configuration only
+        c.cfg = surreal_config(**kw)
+        return c
+    ref_kwargs = {"pts_tr_fn": WorldToLocalEncoder(), "kp_input_fn": RelDistEncoder(), "view_input_fn": VecNormEncoder(),
+                  "bone_input_fn": VecNormEncoder(), "density_scale": 1.0, "density_fn": F.relu}
+    caster()._check_preproc_kwargs(ref_kwargs)          # what create_raycaster builds for the shipped configs: accepted
+    caster()._check_preproc_kwargs({})
+    with pytest.raises(NotImplementedError, match="RayAngEncoder"):
+        caster()._check_preproc_kwargs(dict(ref_kwargs, view_input_fn=RayAngEncoder()))
+    with pytest.raises(ValueError, match="density_scale"):
+        caster()._check_preproc_kwargs(dict(ref_kwargs, density_scale=0.5))
+    softplus = lambda x: F.softplus(x - 1.0, beta=1)    # get_density_fn's lambda (raycasters.py:233-236)
+    with pytest.raises(NotImplementedError, match="density_fn"):
+        caster()._check_preproc_kwargs(dict(ref_kwargs, density_fn=softplus))
+    caster(density_type="softplus", softplus_shift=1.0)._check_preproc_kwargs(dict(ref_kwargs, density_fn=softplus))
+    with pytest.raises(NotImplementedError, match="density_fn"):
+        caster(density_type="softplus", softplus_shift=0.5)._check_preproc_kwargs(dict(ref_kwargs, density_fn=softplus))
+    with pytest.raises(NotImplementedError, match="not supported"):
+        caster()._check_preproc_kwargs({"subject_fn": object()})
+    with pytest.raises(NotImplementedError, match="undefined"):
+        _density_act("elu")
+
+
+def test_box_pixel_ids_are_the_reference_valid_idxs_built_lazily():
+    """rays.BoxPixelIds (the `valid_idxs` render_path returns) == kp_to_boxes' materialised ids, and the host-route
+    frame_boxes == kp_to_boxes' boxes."""
+    from posegen_amd import synthetic as syn
+    from posegen_amd.rays import BoxPixelIds, frame_boxes, kp_to_boxes
+    H = W = 96
+    _, kps, _ = syn.make_pose(3, 11)
+    c2ws, focals = syn.make_camera(3, H, W)
+    cyls, bboxes, grids = kp_to_boxes(torch.tensor(c2ws), H, W, focals, kps=torch.tensor(kps), ext_scale=0.001)
+    lazy = BoxPixelIds(bboxes, [g[3] for g in grids])
+    assert len(lazy) == 3 and lazy._cache == {}
+    assert lazy.counts() == [len(g[0]) for g in grids] and lazy._cache == {}
+    for i, (rows, cols, h, w, *_rest) in enumerate(grids):
+        assert torch.equal(lazy[i], rows * w + cols)
+    assert sum(len(v) for v in lazy) == sum(lazy.counts())
+    c2, b2, meta = frame_boxes(object(), torch.tensor(c2ws), H, W, focals, kps=torch.tensor(kps), ext_scale=0.001)   # no pose_boxes: host route
+    assert torch.equal(torch.as_tensor(c2), torch.as_tensor(cyls))
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(b2, bboxes))
+    assert [m[:2] for m in meta] == [(H, W)] * 3

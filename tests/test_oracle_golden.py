@@ -9,7 +9,7 @@ from posegen_amd import synthetic as syn
 from tests.helpers import (cfg_from_golden, golden_draws, load_golden, model_for, oracle_cfg,
                            oracle_render_rays, torch_weights, weights_digest)
 
-RAY_CASES = ["rays_surreal", "rays_allhit", "rays_coarse32", "rays_cfg1", "rays_h36m"]
+RAY_CASES = ["rays_surreal", "rays_allhit", "rays_coarse32", "rays_cfg1", "rays_h36m", "rays_softplus"]
 # fp32 end to end on both sides; differences are summation-order only
 TOL = dict(rtol=2e-5, atol=2e-6)
 
@@ -133,7 +133,7 @@ def _loss_of(out, target):
     return loss
 
 
-@pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m"])
+@pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m", "train_grads_softplus", "train_grads_raw"])
 def test_oracle_autograd_matches_the_reference_training_gradients(name):
     """The oracle under torch autograd against the reference's own `loss.backward()` (fixture from
     tools/gen_golden.py: Trainer-style MSE on a training-mode call with pytest=True draws): every parameter
@@ -141,6 +141,8 @@ def test_oracle_autograd_matches_the_reference_training_gradients(name):
     HIP backward pass is tested against."""
     from tools.gen_golden import grad_sample_index
     g = load_golden(name)
+    # train_grads_raw: the un-filtered batch -- bound from the stored sensitivity of the reference's own gradient
+    tol = max(1e-4, 4.0 * float(g["grad_sensitivity"])) if name == "train_grads_raw" else 1e-4
     cfg = cfg_from_golden(g)
     wc, wf, tv, td = model_for(cfg, int(g["seed_model"]))
     tw = lambda w: {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
@@ -160,7 +162,7 @@ def test_oracle_autograd_matches_the_reference_training_gradients(name):
             got = p.grad.numpy().reshape(-1)
             scale = max(float(np.abs(ref_vals).max()), ref_norm / np.sqrt(got.size), 1e-12)
             err = float(np.abs(got[grad_sample_index(got.size)] - ref_vals).max())
-            assert err <= 1e-4 * scale + 1e-9, (tag, k, err, scale)
-            assert abs(float(np.linalg.norm(got.astype(np.float64))) - ref_norm) <= 1e-4 * ref_norm + 1e-9, (tag, k)
+            assert err <= tol * scale + 1e-9, (tag, k, err, scale)
+            assert abs(float(np.linalg.norm(got.astype(np.float64))) - ref_norm) <= tol * ref_norm + 1e-9, (tag, k)
             n_checked += 1
     assert n_checked == (50 if cfg.framecode_ch else 48)
