@@ -54,6 +54,13 @@ struct RecArgs {
     int n_codes;
 };
 
+// slot16_joint as a device table lookup (a constexpr array indexed at run time)
+__device__ __forceinline__ int slot_joint_dev(int s) {
+    constexpr unsigned long long lo = []{ unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)PERM16[i] << (5 * i); return v; }();
+    constexpr unsigned long long hi = []{ unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)PERM16[12 + i] << (5 * i); return v; }();
+    return (int)(((s < 12 ? lo : hi) >> (5 * (s < 12 ? s : s - 12))) & 31);
+}
+
 // The opt-in to > 64 KiB of dynamic LDS is per (kernel, device): set once per device, from any host
 // thread (pg_render_frames drives one thread per device).
 inline hipError_t ensure_lds_attr(const void* fn, int bytes, std::atomic<unsigned long long>& done) {

@@ -53,8 +53,8 @@ using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES>;
 // LDS carve-up of this kernel (bytes)
 constexpr int LDSR_RING = 0;
 constexpr int LDSR_BIAS = PG_RING_SLOTS * CHUNK_BYTES;          // BIAS16_FLOATS floats
-constexpr int LDSR_CUT = LDSR_BIAS + BIAS16_FLOATS * 4;         // 48 floats
-constexpr int LDSR_AB = LDSR_CUT + 48 * 4;                      // two buffers of LDS_AB_BYTES: this pass / the next
+constexpr int LDSR_CUT = LDSR_BIAS + BIAS16_FLOATS * 4;         // 72 floats, by joint SLOT: cutoff constants of embed_fn, of embeddirs_fn, far^2
+constexpr int LDSR_AB = LDSR_CUT + 72 * 4;                      // two buffers of LDS_AB_BYTES: this pass / the next
 constexpr int LDSR_Y = LDSR_AB + 2 * LDS_AB_BYTES;              // MAXR_F rays x REC_Y_BYTES
 constexpr int LDSR_TOTAL = LDSR_Y + MAXR_F * REC_Y_BYTES;
 static_assert(LDSR_BIAS % 16 == 0 && LDSR_CUT % 16 == 0 && LDSR_AB % 16 == 0 && LDSR_Y % 16 == 0, "LDS alignment");
@@ -92,72 +92,56 @@ __device__ __forceinline__ void mma_row16(f32x4 (*acc)[2], APipe<V, NS>& p, ST& 
     }
 }
 
-// acc += W[:, x-columns] x for the wave's two column tiles; X16 sequence of pg_layout.h: joints 0..3 (two units
-// each), their leftovers, joints 4, 5, their leftovers.  `ab0` / `ab1`: LDS byte address of the (a, b) row of the lane
-// group's first joint for the two points; the rows of joint jj + 1 are fetched beside the ring pipe (lds_async128)
-// while joint jj is multiplied.  `hook` runs once behind the first unit row, i.e. behind the segment's first chunk
-// entry (the per-pass record fetch of layer 0 hangs there).
+// acc += W[:, x-columns] x for the wave's two column tiles; X16 sequence of pg_layout.h: per joint slot jj of the lane
+// group two units of cutoff-weighted values (one chunk of the stream = the four joints of one LIMB), then three units
+// of directions.  `farmask` bit jj (wave-uniform): limb jj is out of cutoff range of all 32 points of the wave --
+// every value of its two units is w_j(point) x (...) with w_j = 1 / (1 + 2^t), t >= 24, i.e. below 6e-8 (the
+// reference's 1 - sigmoid rounds to exactly 0 there) -- so the wave only keeps the ring going for that chunk (entry,
+// its share of the refill) and runs neither the embedding math nor the 64 MFMAs.  At tau = 79.6 (a trained model,
+// cutoff_embedder.py:181-183) 88 % of the limb chunks of a frame are skipped: a point is near 1-2 limbs.
+// `hook` runs once behind the segment's first chunk entry (the per-pass record fetch of layer 0 hangs there).
 template <typename V, typename ST, typename HOOK>
 __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float* abp0, const float* abp1, float z0, float z1,
-                                            const float* cutv, float tau, HOOK hook) {
+                                            const float* cutv, float tau, int farmask, HOOK hook) {
     APipeX<V> p;
     constexpr int T = XU16 * NT16;
-    // values 16, 17 of four joints make one more unit: kept as packed 16-bit pairs (4 + 4 registers instead of 16)
-    unsigned lo0[4] = {0u, 0u, 0u, 0u}, lo1[4] = {0u, 0u, 0u, 0u};
-    auto pack2 = [](float a, float b) {
-        using E = typename Op<V>::E;
-        typedef E e2 __attribute__((ext_vector_type(2)));
-        const e2 v = {(E)a, (E)b};
-        return __builtin_bit_cast(unsigned, v);
-    };
-    int uu = 0;
-#if PG_R_ASYNC_AB
-    const unsigned ab0 = lds_addr_of(abp0), ab1 = lds_addr_of(abp1);
-    a128 ab[2][4];          // [joint parity][point 0 lo, hi, point 1 lo, hi]: (a, pad) and (b, pad)
-    auto fetch = [&](int jj) {
-        lds_async128(ab[jj & 1][0], ab0 + jj * 32);
-        lds_async128(ab[jj & 1][1], ab0 + jj * 32 + 16);
-        lds_async128(ab[jj & 1][2], ab1 + jj * 32);
-        lds_async128(ab[jj & 1][3], ab1 + jj * 32 + 16);
-    };
-    fetch(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the ring pipe is empty between segments
-#else
+    static_assert(2 * NT16 == pgp::R::UPC, "a limb's two unit rows are exactly one chunk of the stream");
     const QFromAB q0{abp0, z0}, q1{abp1, z1};
-#endif
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < JG; ++jj) {
-        float x0[18], x1[18];
-#if PG_R_ASYNC_AB
-        if (jj + 1 < JG) fetch(jj + 1);
+        if ((farmask >> jj) & 1) {
+            st.enter_split();
+            if (jj == 0) hook();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lds_landed(ab[jj & 1][k]);
-        {
-            const float4 lo = __builtin_bit_cast(float4, ab[jj & 1][0]), hi = __builtin_bit_cast(float4, ab[jj & 1][1]);
-            joint_values_q<true>(fmaf(z0, hi.x, lo.x), fmaf(z0, hi.y, lo.y), fmaf(z0, hi.z, lo.z), tau, cutv[jj], x0);
+            for (int i = 0; i < ST::PER; ++i) st.piece(i);
+            continue;
         }
-        {
-            const float4 lo = __builtin_bit_cast(float4, ab[jj & 1][2]), hi = __builtin_bit_cast(float4, ab[jj & 1][3]);
-            joint_values_q<true>(fmaf(z1, hi.x, lo.x), fmaf(z1, hi.y, lo.y), fmaf(z1, hi.z, lo.z), tau, cutv[jj], x1);
-        }
-#else
+        float x0[18], x1[18];
         float qx, qy, qz;
         q0(jj, qx, qy, qz);
         joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x0);
         q1(jj, qx, qy, qz);
         joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x1);
-#endif
-        const int k = jj < 4 ? jj : jj - 4;
-        lo0[k] = pack2(x0[16], x0[17]);
-        lo1[k] = pack2(x1[16], x1[17]);
-        mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0), Op<V>::cvt(x1));
+        x0[15] = x1[15] = 0.0f;             // (the directions x[15..17] have units of their own)
+        mma_row16<V, NT16, T>(acc, p, st, 2 * jj, Op<V>::cvt(x0), Op<V>::cvt(x1));
         if (jj == 0) hook();
-        mma_row16<V, NT16, T>(acc, p, st, uu++, Op<V>::cvt(x0 + 8), Op<V>::cvt(x1 + 8));
-        if (jj == 3 || jj == JG - 1) {
-            if (jj == JG - 1) { lo0[2] = lo0[3] = 0u; lo1[2] = lo1[3] = 0u; }
-            const u32x4 l0 = {lo0[0], lo0[1], lo0[2], lo0[3]}, l1 = {lo1[0], lo1[1], lo1[2], lo1[3]};
-            mma_row16<V, NT16, T>(acc, p, st, uu++, __builtin_bit_cast(V, l0), __builtin_bit_cast(V, l1));
-        }
+        mma_row16<V, NT16, T>(acc, p, st, 2 * jj + 1, Op<V>::cvt(x0 + 8), Op<V>::cvt(x1 + 8));
+    }
+    // r = q / max(|q|, 1e-12) of every joint (VecNormEncoder on the bone-local position, encoders.py:172-193): not
+    // cutoff-weighted, always there
+    auto dir = [](const QFromAB& q, int jj, float* r3) {
+        float qx, qy, qz;
+        q(jj, qx, qy, qz);
+        const float rinv = __builtin_amdgcn_rsqf(fmaxf(qx * qx + qy * qy + qz * qz, 1e-24f));
+        r3[0] = qx * rinv; r3[1] = qy * rinv; r3[2] = qz * rinv;
+    };
+#pragma clang loop unroll(full)
+    for (int pr = 0; pr < JG / 2; ++pr) {
+        float v0[8], v1[8];
+        dir(q0, 2 * pr, v0); dir(q0, 2 * pr + 1, v0 + 3);
+        dir(q1, 2 * pr, v1); dir(q1, 2 * pr + 1, v1 + 3);
+        v0[6] = v0[7] = v1[6] = v1[7] = 0.0f;
+        mma_row16<V, NT16, T>(acc, p, st, XV16 + pr, Op<V>::cvt(v0), Op<V>::cvt(v1));
     }
 }
 
@@ -192,9 +176,6 @@ __device__ __forceinline__ void row_tile16(f32x4& acc0, f32x4& acc1, APipe<V, NS
     }
 }
 
-#ifndef PG_R_ASYNC_AB
-#define PG_R_ASYNC_AB 0       // (a, b) rows of the next joint fetched beside the ring pipe (16 more live registers)
-#endif
 #ifndef PG_R_PACK_AT
 #define PG_R_PACK_AT 2        // unit of an even tile behind which the previous tile pair is converted
 #endif
@@ -283,7 +264,10 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
 
     for (int i = tid; i < BIAS16_FLOATS; i += NTHR) bias[i] = a.bias[i];
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
-    if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    // by joint SLOT (pg_layout.h slot16_joint): the folded sigmoid constants of both embedders, and the squared distance
+    // beyond which a joint's cutoff weight 1 / (1 + 2^(v tl + cs)) is below 2^-24
+    if (tid < 48) cut[tid] = -a.cutoff[(tid < J ? 0 : J) + slot_joint_dev(tid < J ? tid : tid - J)] * (tid < J ? tlv : tld);
+    else if (tid < 72) { const float far = a.cutoff[slot_joint_dev(tid - 48)] + 24.0f / tlv; cut[tid] = far * far; }
     st.start();
 #if defined(PG_YOUNG_PRIO)
     // experiment: the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what
@@ -351,6 +335,23 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         float cutv[JG];                         // the lane group's folded cutoff constants (6 registers)
 #pragma unroll
         for (int jj = 0; jj < JG; ++jj) cutv[jj] = cut[JG * g_p + jj];
+        // limbs out of cutoff range of every point of the wave (x_segment16): one ballot per joint slot over the four
+        // lane groups' joints and the 2 x 16 points
+        int farmask = 0;
+#if !defined(PG_NO_FAR_SKIP)
+        {
+            const float* far2 = opaque_ptr(cut + 2 * J + JG * g_p);
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj) {
+                float ax, ay, az, bx, by, bz;
+                q0(jj, ax, ay, az);
+                q1(jj, bx, by, bz);
+                const bool near = fminf(ax * ax + ay * ay + az * az, bx * bx + by * by + bz * bz) < far2[jj];
+                if (__builtin_amdgcn_ballot_w64(near) == 0ull) farmask |= 1 << jj;
+            }
+            farmask = __builtin_amdgcn_readfirstlane(farmask);
+        }
+#endif
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the
         // (a, b) buffer of the pass before may be overwritten.  Wave w fetches out tile w of this pass's MAXR_F Y
         // records and waves 0..3 a piece of the NEXT pass's (a, b); both are in LDS, and visible, one chunk entry on.
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             f32x4 acc[NT16][2];
 #pragma unroll
             for (int o = 0; o < NT16; ++o) acc[o][0] = acc[o][1] = load_bias16(bias, BS_LAYER0 + o, g);
-            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, fetch_records);
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, fetch_records);
             if (TAPS && a.dbg && a.dbg_stage == 0) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                     if (u == PG_R_BIAS_AT && o + 1 < NT16) bp.fetch(o + 1);
                 }
             }
-            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, [] {});
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, [] {});
 #pragma unroll
             for (int u = 0; u < HU16; ++u)
 #pragma unroll

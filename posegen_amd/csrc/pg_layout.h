@@ -122,8 +122,9 @@ PG_HD constexpr int vd_channel(int j, int k) {
     if (j < J) return k < 3 * ROWS_D ? (k % ROWS_D) * (3 * J) + 3 * j + k / ROWS_D : -1;
     return k < FC_CH ? CH_D + k : -1;
 }
-// joint the Y-stage wave w (half w>>2) handles as its e-th (0..12); -1 = none
-PG_HD constexpr int vy_joint(int w, int e, bool fc) {
+// joint the Y-stage wave w (half w>>2) handles as its e-th (0..12): the joint of SLOT 12 (w>>2) + e of the 16x16x32
+// kernel's slot order (slot16_joint below); -1 = none
+PG_HD constexpr int vy_slot(int w, int e, bool fc) {
     return e < JH ? JH * (w >> 2) + e : ((fc && (w >> 2) == 0 && e == JH) ? JC : -1);
 }
 
@@ -148,24 +149,35 @@ constexpr int JG = J / G16;             // 6 joints per lane group
 constexpr int NT16 = W / 16;            // 16 out tiles of the trunk
 constexpr int NTV16 = VW / 16;          // 8 of the view layer
 constexpr int HU16 = W / 32;            // 8 k-units of a trunk activation
-constexpr int XU16 = 14;                // k-units of the density input: 6 joints x 18 = 108 -> 112
+constexpr int XU16 = 15;                // k-units of the density input: 6 joint slots x 16 (15 used) + 3 units of directions
 constexpr int XSEQ16 = XU16 * 8;
 PG_HD constexpr int hseq16_channel(int i, int g) { return 16 * (2 * (i / 8) + ((i % 8) >> 2)) + 4 * g + (i & 3); }
-// density-input column of X16-sequence index i of lane group g, in generation order: joints
-// 0..3 (units 0..7: values 0..15), unit 8 = their values 16, 17; joints 4, 5 (units 9..12),
-// unit 13 = their values 16, 17 and 4 zero pads
+// Joint of slot s = 6 g + jj (lane group g, its jj-th joint).  A k-unit of the density input holds slot jj of all
+// four lane groups, i.e. the four joints {PERM16[jj], PERM16[6 + jj], PERM16[12 + jj], PERM16[18 + jj]}: they are
+// chosen as one LIMB each (left leg, right leg, left arm, right arm, spine, head / collars), because a wave skips the
+// units of a limb that is out of cutoff range of all its 32 points (pg_eval16r.hip: the cutoff weight
+// 1 - sigmoid(tau (v - c)), cutoff_embedder.py:139-146, is exactly zero in fp32 beyond c + 24 / (tau log2 e)) --
+// with SMPL's joint order (pelvis, l/r hip, spine1, l/r knee, spine2, l/r ankle, spine3, l/r foot, neck, l/r collar,
+// head, l/r shoulder, l/r elbow, l/r wrist, l/r hand) as the slot order a unit would mix four body regions.
+constexpr int PERM16[24] = {1, 2, 16, 17, 0, 12,  4, 5, 18, 19, 3, 13,  7, 8, 20, 21, 6, 14,  10, 11, 22, 23, 9, 15};
+PG_HD constexpr int slot16_joint(int s) { return PERM16[s]; }
+constexpr int XV16 = 2 * JG;            // units 0 .. 11: the cutoff-weighted values (skippable per limb)
+// density-input column of X16-sequence index i of lane group g, in generation order: units 2 jj, 2 jj + 1 = values
+// q = 0..14 of slot jj (v w, sin / cos of the 7 octaves times w) and one zero pad; units 12 + p = the directions
+// r_xyz (values 15..17, not cutoff-weighted) of slots 2 p and 2 p + 1 and two zero pads
 PG_HD constexpr int xseq16_channel(int i, int g) {
-    int u = i / 8, e = i % 8, jj = 0, q = 0;
-    if (u < 8) { jj = u / 2; q = 8 * (u % 2) + e; }
-    else if (u == 8) { jj = e / 2; q = 16 + e % 2; }
-    else if (u < 13) { jj = 4 + (u - 9) / 2; q = 8 * ((u - 9) % 2) + e; }
-    else { if (e >= 4) return -1; jj = 4 + e / 2; q = 16 + e % 2; }
-    int j = JG * g + jj;
-    return q < ROWS_V ? q * J + j : CH_V + 3 * j + (q - ROWS_V);
+    int u = i / 8, e = i % 8;
+    if (u < XV16) {
+        int q = 8 * (u % 2) + e;
+        if (q >= ROWS_V) return -1;
+        return q * J + slot16_joint(JG * g + u / 2);
+    }
+    if (e >= 6) return -1;
+    return CH_V + 3 * slot16_joint(JG * g + 2 * (u - XV16) + e / 3) + e % 3;
 }
 // second stage of the factorised view layer: joint in slot e of lane group g (-1 = zero)
 PG_HD constexpr int vy16_slot_joint(int g, int e, bool fc) {
-    return e < JG ? JG * g + e : ((fc && g == 0 && e == JG) ? JC : -1);
+    return e < JG ? slot16_joint(JG * g + e) : ((fc && g == 0 && e == JG) ? JC : -1);
 }
 // bias tiles of 16 rows, [tile][g][4]: L0..L7 (16 each), alpha, folded view (8), rgb
 constexpr int BS_LAYER0 = 0;
@@ -180,7 +192,8 @@ constexpr int BIAS16_FLOATS = BS_COUNT * 16;
 // the fused one and handed over through HBM in the exact LDS image the fused kernel wants, so that a workgroup
 // pass fetches it with a handful of LDS-DMA pieces instead of building it (table build + Y stage + two barriers
 // per pass, and 192 KiB of Y-stage weights through the vector memory path per pass, were 13 % of a pass):
-//   AB[ray][joint] = (a = R_j o + t_j, pad, b = R_j d, pad)  8 floats: q = a + z b          (REC_AB_BYTES per ray)
+//   AB[ray][slot] = (a = R_j o + t_j, pad, b = R_j d, pad)  8 floats: q = a + z b, j = slot16_joint(slot)
+//                                                                                          (REC_AB_BYTES per ray)
 //   Y [ray][out tile16 t][lane (g, row)] x 16 B = the 8 joint slots of lane group g (vy16_slot_joint) of
 //       Y[ray][j][16 t + row] = sum_k W_vd[16 t + row, (j, k)] T[ray][j][k]                     (REC_Y_BYTES per ray)
 // Both arrays carry REC_PAD_RAYS rays of slack at the end: a pass always fetches MAXR_F rays.

@@ -218,8 +218,9 @@ int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& o
     out.assign((size_t)R::VY_BYTES(fc), 0);
     for (int w = 0; w < 8; ++w)
         for (int n = 0; n < R::VY_UNITS(fc); ++n) {
-            const int j = vy_joint(w, n / 2, fc), ku = n % 2;
-            if (j < 0) continue;
+            const int sl = vy_slot(w, n / 2, fc), ku = n % 2;
+            if (sl < 0) continue;
+            const int j = sl == JC ? JC : slot16_joint(sl);
             const size_t base = ((size_t)w * R::VY_UNITS(fc) + n) * UNIT_BYTES;
             // lane (hl, col) = out channel 32(w&3)+col, values k = 16ku + 8hl + 0..7 of joint j
             for (int lane = 0; lane < 64; ++lane)

@@ -39,7 +39,7 @@ void pack_bias(const NetTensors& t, std::vector<float>& out);
 int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out);
 void pack_bias_s(const NetTensors& t, std::vector<float>& out);
 // Y-stage weights of the record kernel (pg_rayrec.hip): [wave 8][unit n][64 lanes x 16 B]; unit n of
-// wave w = (joint vy_joint(w, n/2), k-unit n%2) of out tile w&3 as an MFMA B operand.
+// wave w = (joint slot16_joint(vy_slot(w, n/2)), k-unit n%2) of out tile w&3 as an MFMA B operand.
 int pack_vy(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out);
 // fp32 Y-stage weights of the compensated-fp16 record kernel: [joint 0..24][VYC_K][128 out channels],
 // W_vd[o, (j, k)] for value k = c * 9 + row of joint j (vd_channel), joint 24 = the frame code

@@ -56,12 +56,12 @@ constexpr int MFMA_PER_GROUP(bool fc) {
 // The view-direction part of the view layer comes from the per-ray Y records (pg_layout.h), not from the stream.
 namespace R {
 constexpr int UPC = CHUNK_BYTES / UNIT_BYTES;
-constexpr int CH_L0X = cdiv(XU16 * NT16, UPC);          // 7
+constexpr int CH_L0X = cdiv(XU16 * NT16, UPC);          // 8: one chunk per limb (6), then the directions
 constexpr int CH_HID = cdiv(HU16 * NT16, UPC);          // 4
 constexpr int U_AV = HU16 * (NTV16 + 1);                // 72 units: alpha tile + 8 folded view tiles
 constexpr int U_RGB = VW / 32;                          // 4 units, directly behind (no chunk padding in between)
 constexpr int CH_AVR = cdiv(U_AV + U_RGB, UPC);         // 3
-constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 45
+constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 47
 // 16x16x32 MFMAs per 32-point group: two per unit, plus the second stage of the view layer for one ray
 constexpr int MFMA16_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + U_AV + U_RGB) + 2 * NTV16;
 // Y-stage weights of the record kernel (pg_rayrec.hip): per wave (out tile w&3, joint half w>>2) two B fragments

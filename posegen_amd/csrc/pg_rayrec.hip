@@ -52,6 +52,7 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
         const int r0 = tile * REC_TILE_RAYS;
         __syncthreads();                        // the previous tile's table has been read
         // ---- phase 1: one thread per (ray, joint): (a, b) to HBM, the 27 view values T to LDS as MFMA operands ----
+        // (records are laid out by SLOT of the 16x16x32 kernel: slot s holds joint slot16_joint(s), pg_layout.h)
         for (int idx = tid; idx < REC_TILE_RAYS * NJ; idx += REC_THREADS) {
             const int rr = idx / NJ, j = idx - rr * NJ;
             const bool live = r0 + rr < a.n_rays;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
 #pragma unroll
             for (int k = 0; k < TK; ++k) tv[k] = 0.0f;
             if (j < J) {
-                const float4* sk = reinterpret_cast<const float4*>(a.skts + ray * a.pose_stride + j * 16);
+                const float4* sk = reinterpret_cast<const float4*>(a.skts + ray * a.pose_stride + slot_joint_dev(j) * 16);
                 const float4 ra = sk[0], rb = sk[1], rc = sk[2];
                 const float* ry = a.rays + ray * 11;
                 const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
         }
         __syncthreads();
         // ---- phase 2: Y = T W, rays as MFMA rows; C has the out channel on the lane and 16 rays in registers.
-        // Joint e of the wave (joint 12 hw + e; e = 12: the frame code) is slot e % 6 of lane group 2 hw + e / 6 of
+        // Slot e of the wave (slot 12 hw + e of the T table; e = 12: the frame code) is slot e % 6 of lane group 2 hw + e / 6 of
         // the second stage's A fragment (vy16_slot_joint); the code sits in slot 6 of group 2 hw (zero weights, hence
         // a zero, for hw = 1).  One 16-byte store per ray and lane group. ----
         const uint8_t* trow = t16 + col * REC_TSTRIDE + hl * 16;

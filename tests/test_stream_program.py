@@ -120,8 +120,12 @@ def vd_channel(j, k):
     return 648 + k if k < 16 else -1
 
 
+PERM16 = [1, 2, 16, 17, 0, 12, 4, 5, 18, 19, 3, 13, 7, 8, 20, 21, 6, 14, 10, 11, 22, 23, 9, 15]     # pg_layout.h: slot -> joint
+
+
 def vy_joint(w, e, fc):
-    return JH * (w >> 2) + e if e < JH else (J if fc and (w >> 2) == 0 and e == JH else -1)
+    """joint the Y-stage wave w handles as its e-th: the joint of SLOT 12 (w >> 2) + e (pg_layout.h vy_slot / slot16_joint)"""
+    return PERM16[JH * (w >> 2) + e] if e < JH else (J if fc and (w >> 2) == 0 and e == JH else -1)
 
 
 def vy_slot_joint(u, h, e, fc):
@@ -243,7 +247,7 @@ def emulate(stream, bias, chunk_bytes, prec, x, cfg, fact=None):
 
 
 # ---- the 16x16x32 program of pg_eval16r.hip (pg_program.h R, pg_layout.h "small tile") ----
-JG, NT16, NTV16, HU16, XU16 = 6, 16, 8, 8, 14
+JG, NT16, NTV16, HU16, XU16, XV16 = 6, 16, 8, 8, 15, 12
 BS_ALPHA, BS_VIEWF, BS_RGB = 128, 129, 137
 
 
@@ -252,23 +256,19 @@ def hseq16_channel(i, g):
 
 
 def xseq16_channel(i, g):
+    """pg_layout.h xseq16_channel: units 2 jj, 2 jj + 1 = the 15 cutoff-weighted values of joint slot jj (+ a pad),
+    units 12 + p = the directions of slots 2 p, 2 p + 1 (+ two pads); slot 6 g + jj holds joint PERM16[6 g + jj]"""
     u, e = divmod(i, 8)
-    if u < 8:
-        jj, q = u // 2, 8 * (u % 2) + e
-    elif u == 8:
-        jj, q = e // 2, 16 + e % 2
-    elif u < 13:
-        jj, q = 4 + (u - 9) // 2, 8 * ((u - 9) % 2) + e
-    else:
-        if e >= 4:
-            return -1
-        jj, q = 4 + e // 2, 16 + e % 2
-    j = JG * g + jj
-    return q * J + j if q < 15 else 360 + 3 * j + (q - 15)
+    if u < XV16:
+        q = 8 * (u % 2) + e
+        return q * J + PERM16[JG * g + u // 2] if q < 15 else -1
+    if e >= 6:
+        return -1
+    return 360 + 3 * PERM16[JG * g + 2 * (u - XV16) + e // 3] + e % 3
 
 
 def vy16_slot_joint(g, e, fc):
-    return JG * g + e if e < JG else (J if fc and g == 0 and e == JG else -1)
+    return PERM16[JG * g + e] if e < JG else (J if fc and g == 0 and e == JG else -1)
 
 
 def emulate_r(stream, bias16, chunk_bytes, prec, x, cfg, fact):
