@@ -329,6 +329,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
         ra.rays = rays; ra.skts = skts; ra.cams = cams; ra.codes = a.codes; ra.wy = a.wy;
         ra.rec_ab = const_cast<float*>(a.rec_ab); ra.rec_y = const_cast<uint8_t*>(a.rec_y);
         ra.pose_stride = pose_stride; ra.n_rays = (int)n; ra.n_codes = ns.n_codes;
+        ra.z = z; ra.S = S;
         hipEvent_t x0 = nullptr, x1 = nullptr;
         if (h->profiling) { PG_HIP(h, get(x0)); PG_HIP(h, get(x1)); PG_HIP(h, hipEventRecord(x0, static_cast<hipStream_t>(stream))); }
         const int er = crec ? pg_launch_ray_records_c(&ra, fc, h->n_cu, stream) : pg_launch_ray_records(&ra, prec == PG_PREC_FP16, fc, h->n_cu, stream);

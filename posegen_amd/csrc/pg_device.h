@@ -49,9 +49,11 @@ struct RecArgs {
     const uint8_t* wy;        // Y-stage weights (pack_vy)
     float* rec_ab;            // [n + REC_PAD_RAYS][24][8]
     uint8_t* rec_y;           // [n + REC_PAD_RAYS][REC_Y_BYTES]
+    const float* z;           // [n,S] depths of the launch the records are for (the per-joint distance bound below)
     long long pose_stride;
     int n_rays;
     int n_codes;
+    int S;
 };
 
 // slot16_joint as a device table lookup (a constexpr array indexed at run time)
@@ -98,7 +100,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // others just synchronise.  The oldest wave of each SIMD wins issue arbitration and reaches
 // every chunk barrier early: giving those waves all of the refill work (NDMA = NWAVE/2) moves
 // its issue cost off the critical wave of the SIMD.
-template <int NWAVE, int NCHUNK_, int NDMA = NWAVE>
+// MASK_NX > 0 (pg_eval16r.hip): chunks MASK_X0 + k and MASK_X1 + k (k < MASK_NX) of the stream hold the weights of one
+// LIMB each; chunk k of both ranges is left out of a pass's chunk sequence when bit k of the pass's mask is set (no
+// workgroup point is within cutoff range of the limb: nothing would read it).  The mask must be the same in every
+// wave.  `pf_mask` is the mask of the pass the prefetch pointer is in, `nx_mask` that of the pass behind it (taken
+// over when the pointer wraps to the head of the stream).
+template <int NWAVE, int NCHUNK_, int NDMA = NWAVE, int MASK_NX = 0, int MASK_X0 = 0, int MASK_X1 = 0>
 struct Stream {
     static constexpr int NSLOT = PG_RING_SLOTS;
     static constexpr int DEPTH = NSLOT - 1;
@@ -115,6 +122,25 @@ struct Stream {
     uint32_t rd_off;       // this lane's byte offset into the ring for the current chunk
     uint32_t ring_lds;     // LDS byte address of the ring (for asm ds_read)
     uint32_t lane16;       // lane * 16
+    uint32_t pf_mask = 0u, nx_mask = 0u;
+
+    // next_off: one chunk on in the (masked) sequence.  Scalar arithmetic only.
+    __device__ __forceinline__ void skip_masked() {
+        if constexpr (MASK_NX > 0) {
+            const uint32_t c = next_off / CHUNK_BYTES;
+            const uint32_t k0 = c - (uint32_t)MASK_X0, k1 = c - (uint32_t)MASK_X1;
+            const uint32_t k = k0 < (uint32_t)MASK_NX ? k0 : k1;
+            // bits >= MASK_NX of a mask are zero: the run of set bits from k ends inside the limb range
+            if (k < (uint32_t)MASK_NX) next_off += (uint32_t)__builtin_ctz(~(pf_mask >> k)) * CHUNK_BYTES;
+        }
+    }
+    __device__ __forceinline__ void advance() {
+        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        if constexpr (MASK_NX > 0) {
+            if (next_off == 0u) pf_mask = nx_mask;
+            skip_masked();
+        }
+    }
 
     __device__ __forceinline__ bool dma_wave() const { return NDMA == NWAVE || (wave >= dma_base() && wave < dma_base() + NDMA); }
     static constexpr int dma_base() { return NDMA == NWAVE ? 0 : PG_DMA_BASE; }
@@ -125,14 +151,17 @@ struct Stream {
 #pragma unroll
             for (int i = 0; i < PER; ++i) glds16(src + i * 1024, dst + i * 1024);
         }
-        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        advance();
         fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
         asm volatile("" : "+s"(next_off), "+s"(fill_slot));
     }
     // kernel start: DEPTH chunks in flight; the first enter() consumes slot 0
-    __device__ __forceinline__ void start() {
+    // first_mask: the mask of the first pass (masked streams)
+    __device__ __forceinline__ void start(uint32_t first_mask = 0u) {
         next_off = 0;
         fill_slot = 0;
+        pf_mask = nx_mask = first_mask;
+        skip_masked();
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) prefetch_next();
         rd_off = (uint32_t)(NSLOT - 1) * CHUNK_BYTES + lane * 16;   // advanced by the first enter()
@@ -185,7 +214,7 @@ struct Stream {
 #endif
         cur_src = next_off + (wave - dma_base()) * (PER * 1024);
         cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
-        next_off = next_off + CHUNK_BYTES == (uint32_t)NCHUNK_ * CHUNK_BYTES ? 0u : next_off + CHUNK_BYTES;
+        advance();
         fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
         asm volatile("" : "+s"(next_off), "+s"(fill_slot), "+s"(cur_src), "+s"(cur_dst));
         rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES

@@ -48,7 +48,7 @@ template <> struct Op16<f16x8> {
     }
 };
 
-using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES>;
+using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES, pgp::R::NLIMB, 0, pgp::R::C_L5X>;
 
 // LDS carve-up of this kernel (bytes)
 constexpr int LDSR_RING = 0;
@@ -99,19 +99,23 @@ __device__ __forceinline__ void mma_row16(f32x4 (*acc)[2], APipe<V, NS>& p, ST& 
 // reference's 1 - sigmoid rounds to exactly 0 there) -- so the wave only keeps the ring going for that chunk (entry,
 // its share of the refill) and runs neither the embedding math nor the 64 MFMAs.  At tau = 79.6 (a trained model,
 // cutoff_embedder.py:181-183) 88 % of the limb chunks of a frame are skipped: a point is near 1-2 limbs.
+// `gmask` bit jj (the same in every wave of the workgroup): NO point of the pass is in range of limb jj; its chunk is
+// not in this pass's chunk sequence at all (Stream MASK_NX: never fetched, no entry, no barrier).
 // `hook` runs once behind the segment's first chunk entry (the per-pass record fetch of layer 0 hangs there).
 template <typename V, typename ST, typename HOOK>
 __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float* abp0, const float* abp1, float z0, float z1,
-                                            const float* cutv, float tau, int farmask, HOOK hook) {
+                                            const float* cutv, float tau, int farmask, int gmask, HOOK hook) {
     APipeX<V> p;
     constexpr int T = XU16 * NT16;
     static_assert(2 * NT16 == pgp::R::UPC, "a limb's two unit rows are exactly one chunk of the stream");
     const QFromAB q0{abp0, z0}, q1{abp1, z1};
+    bool hooked = false;                    // wave-uniform
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < JG; ++jj) {
+        if ((gmask >> jj) & 1) continue;
         if ((farmask >> jj) & 1) {
             st.enter_split();
-            if (jj == 0) hook();
+            if (!hooked) { hook(); hooked = true; }
 #pragma unroll
             for (int i = 0; i < ST::PER; ++i) st.piece(i);
             continue;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
         joint_values_q<true>(qx, qy, qz, tau, cutv[jj], x1);
         x0[15] = x1[15] = 0.0f;             // (the directions x[15..17] have units of their own)
         mma_row16<V, NT16, T>(acc, p, st, 2 * jj, Op<V>::cvt(x0), Op<V>::cvt(x1));
-        if (jj == 0) hook();
+        if (!hooked) { hook(); hooked = true; }
         mma_row16<V, NT16, T>(acc, p, st, 2 * jj + 1, Op<V>::cvt(x0 + 8), Op<V>::cvt(x1 + 8));
     }
     // r = q / max(|q|, 1e-12) of every joint (VecNormEncoder on the bone-local position, encoders.py:172-193): not
@@ -142,7 +146,21 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
         dir(q1, 2 * pr, v1); dir(q1, 2 * pr + 1, v1 + 3);
         v0[6] = v0[7] = v1[6] = v1[7] = 0.0f;
         mma_row16<V, NT16, T>(acc, p, st, XV16 + pr, Op<V>::cvt(v0), Op<V>::cvt(v1));
+        if (!hooked) { hook(); hooked = true; }
     }
+}
+
+// Limbs out of cutoff range of EVERY point of a pass, from the per-ray records alone (so that every wave gets the same
+// answer, a pass ahead): AB[ray][slot].w = the squared distance of the ray's sampled segment from the joint
+// (pg_rayrec.hip).  `ab` = the pass's (a, b) buffer in LDS, nrm1 = its last ray; one ballot per joint slot over the
+// four lane groups' joints x the rays of the pass (lane column = ray; columns past the last ray repeat it).
+__device__ __forceinline__ int pass_far_mask(const uint8_t* ab, int nrm1, const float* far2g, int g, int col) {
+    const float* row = opaque_ptr(reinterpret_cast<const float*>(ab + min(col, nrm1) * REC_AB_BYTES) + JG * g * 8 + 3);
+    int m = 0;
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj)
+        if (__builtin_amdgcn_ballot_w64(row[jj * 8] < far2g[jj]) == 0ull) m |= 1 << jj;
+    return __builtin_amdgcn_readfirstlane(m);
 }
 
 // The bias tile of the next out tile, fetched beside the ring pipe: fetch() in front of a next_a() whose successor
@@ -268,7 +286,6 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     // beyond which a joint's cutoff weight 1 / (1 + 2^(v tl + cs)) is below 2^-24
     if (tid < 48) cut[tid] = -a.cutoff[(tid < J ? 0 : J) + slot_joint_dev(tid < J ? tid : tid - J)] * (tid < J ? tlv : tld);
     else if (tid < 72) { const float far = a.cutoff[slot_joint_dev(tid - 48)] + 24.0f / tlv; cut[tid] = far * far; }
-    st.start();
 #if defined(PG_YOUNG_PRIO)
     // experiment: the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what
     // the older one waits for at the chunk barriers: one static priority for that half (no per-segment flips)
@@ -289,6 +306,18 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     int abuf = 0;
+    // limbs no point of the first pass is in range of; every later pass learns its own a pass ahead (below).  The weight
+    // ring starts with that mask: such limbs' chunks are never fetched.
+    auto rays_of_pass = [&](long long p0_, int off0_) {         // index of the pass's last ray among its (<= 5) rays
+        const int last_ = (int)max(0ll, min((long long)PTS - 1, a.n_points - 1 - p0_));
+        const int t_ = off0_ + last_;
+        return (t_ >= a.S) + (t_ >= 2 * a.S) + (t_ >= 3 * a.S) + (t_ >= 4 * a.S);
+    };
+    int gmask = 0;
+#if !defined(PG_NO_FAR_SKIP)
+    gmask = pass_far_mask(smem + LDSR_AB, rays_of_pass(p0, off0), cut + 2 * J + JG * g, g, col);
+#endif
+    st.start((uint32_t)gmask);
 
     // depths of the next pass, fetched a pass ahead (consumed at the top of the pass: one wait finds them there)
     float nx_z[2] = {0.0f, 0.0f};
@@ -371,7 +400,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             f32x4 acc[NT16][2];
 #pragma unroll
             for (int o = 0; o < NT16; ++o) acc[o][0] = acc[o][1] = load_bias16(bias, BS_LAYER0 + o, g);
-            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, fetch_records);
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, gmask, fetch_records);
             if (TAPS && a.dbg && a.dbg_stage == 0) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                     if (u == PG_R_BIAS_AT && o + 1 < NT16) bp.fetch(o + 1);
                 }
             }
-            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, [] {});
+            x_segment16<V>(acc, st, abp[0], abp[1], zz[0], zz[1], cutv, tlv, farmask, gmask, [] {});
 #pragma unroll
             for (int u = 0; u < HU16; ++u)
 #pragma unroll
@@ -422,6 +451,14 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 6 * NT16);
         hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 7 * NT16);
         PG_STAMP(5);
+        // the NEXT pass's limb mask, from its (a, b) records (in LDS since this pass's second chunk entry): the ring's
+        // prefetch pointer wraps to the head of the stream two chunk entries from here and must know it by then
+        int gmask_n = 0;
+#if !defined(PG_NO_FAR_SKIP)
+        gmask_n = pass_far_mask(smem + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES, rays_of_pass(p0 + step, off0n),
+                                opaque_ptr(cut + 2 * J + JG * g_p), g_p, lane_p & 15);
+#endif
+        st.nx_mask = (uint32_t)gmask_n;
         // ---- sigma head + view layer (feature layer folded in, view directions from the Y records) + rgb head,
         // one stream segment: the rgb head's 4 units sit in the chunk the view tiles end in ----
         float sigma[2];
@@ -487,6 +524,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         }
         abuf ^= 1;
         p0 += step; r0 = r0n; off0 = off0n;
+        gmask = gmask_n;
         PG_STAMP(8);
 #if defined(PG_STAMPS)
         if (a.dbg && a.dbg_stage == 99 && lane == 0 && it < 64) {

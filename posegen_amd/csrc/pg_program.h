@@ -62,6 +62,8 @@ constexpr int U_AV = HU16 * (NTV16 + 1);                // 72 units: alpha tile 
 constexpr int U_RGB = VW / 32;                          // 4 units, directly behind (no chunk padding in between)
 constexpr int CH_AVR = cdiv(U_AV + U_RGB, UPC);         // 3
 constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 47
+constexpr int C_L5X = CH_L0X + 5 * CH_HID;              // 28: first chunk of the skip layer's x part (its limb chunks, like layer 0's from 0)
+constexpr int NLIMB = JG;                               // limb chunks at the head of both x segments
 // 16x16x32 MFMAs per 32-point group: two per unit, plus the second stage of the view layer for one ray
 constexpr int MFMA16_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + U_AV + U_RGB) + 2 * NTV16;
 // Y-stage weights of the record kernel (pg_rayrec.hip): per wave (out tile w&3, joint half w>>2) two B fragments

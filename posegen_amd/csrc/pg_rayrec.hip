@@ -27,6 +27,20 @@ template <> struct OpR<f16x8> {
     static __device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+// min over z in [z_first, z_last] of |a + z b|^2: the squared distance of the ray's sampled segment from the joint
+// (bone-local: q = a + z b, encoders.py:8-23), kept in the pad of the record's a row.  The fused kernel leaves a limb's
+// weights out of a pass when this is beyond cutoff range for every ray of the pass (pg_eval16r.hip pass_far_mask).
+__device__ __forceinline__ float segment_dist2(const RecArgs& a, long long ray, float ax, float ay, float az, float bx, float by, float bz) {
+    if (!a.z) return 0.0f;                  // (no depths given: "near")
+    const float z0 = a.z[ray * a.S], z1 = a.z[ray * a.S + a.S - 1];
+    const float bb = bx * bx + by * by + bz * bz, ab = ax * bx + ay * by + az * bz;
+    float zs = bb > 0.0f ? -ab / bb : z0;
+    zs = fminf(fmaxf(zs, fminf(z0, z1)), fmaxf(z0, z1));
+    const float qx = fmaf(zs, bx, ax), qy = fmaf(zs, by, ay), qz = fmaf(zs, bz, az);
+    const float d2 = qx * qx + qy * qy + qz * qz;
+    return d2 == d2 ? d2 : 0.0f;            // NaN depths (never expected): "near"
+}
+
 constexpr int REC_THREADS = 512;
 constexpr int REC_NJT = J + 1;                  // joints per ray in the T table (24 + the frame-code pseudo joint)
 constexpr int REC_TSTRIDE = REC_NJT * TK * 2 + 16;      // bytes per ray (padded: rays 4 apart would share LDS banks)
@@ -71,9 +85,10 @@ __global__ __launch_bounds__(REC_THREADS, 2) void ray_records_kernel(const RecAr
                 e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
                 if (live) {
                     float4* ab = reinterpret_cast<float4*>(a.rec_ab + ray * (REC_AB_BYTES / 4) + j * 8);
-                    ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
-                                        fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
-                                        fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
+                    const float ax = fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
+                                ay = fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
+                                az = fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w)));
+                    ab[0] = make_float4(ax, ay, az, segment_dist2(a, ray, ax, ay, az, e[0], e[1], e[2]));
                     ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
                 }
                 // e = normalize(R_j d); rows (e, sin e, cos e, sin 2e, .., cos 8e) per component c: k = c * 9 + row
@@ -246,9 +261,10 @@ __global__ __launch_bounds__(RECC_THREADS, 1) void ray_records_c_kernel(const Re
                 e[2] = fmaf(rc.z, dz, fmaf(rc.y, dy, rc.x * dx));
                 if (live) {
                     float4* ab = reinterpret_cast<float4*>(a.rec_ab + ray * (REC_AB_BYTES / 4) + j * 8);
-                    ab[0] = make_float4(fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
-                                        fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
-                                        fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w))), 0.0f);
+                    const float ax = fmaf(ra.z, oz, fmaf(ra.y, oy, fmaf(ra.x, ox, ra.w))),
+                                ay = fmaf(rb.z, oz, fmaf(rb.y, oy, fmaf(rb.x, ox, rb.w))),
+                                az = fmaf(rc.z, oz, fmaf(rc.y, oy, fmaf(rc.x, ox, rc.w)));
+                    ab[0] = make_float4(ax, ay, az, segment_dist2(a, ray, ax, ay, az, e[0], e[1], e[2]));
                     ab[1] = make_float4(e[0], e[1], e[2], 0.0f);
                 }
                 const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
