@@ -56,12 +56,15 @@ struct RecArgs {
     int S;
 };
 
-// slot16_joint as a device table lookup (a constexpr array indexed at run time)
-__device__ __forceinline__ int slot_joint_dev(int s) {
-    constexpr unsigned long long lo = []{ unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)PERM16[i] << (5 * i); return v; }();
-    constexpr unsigned long long hi = []{ unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)PERM16[12 + i] << (5 * i); return v; }();
+// slot -> joint tables of pg_layout.h (PERM16, PERMC) as a device lookup at a run-time index: 24 x 5 bits in two constants
+template <const int (&P)[24]>
+__device__ __forceinline__ int perm_dev(int s) {
+    constexpr unsigned long long lo = [] { unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)P[i] << (5 * i); return v; }();
+    constexpr unsigned long long hi = [] { unsigned long long v = 0; for (int i = 0; i < 12; ++i) v |= (unsigned long long)P[12 + i] << (5 * i); return v; }();
     return (int)(((s < 12 ? lo : hi) >> (5 * (s < 12 ? s : s - 12))) & 31);
 }
+__device__ __forceinline__ int slot_joint_dev(int s) { return perm_dev<PERM16>(s); }
+__device__ __forceinline__ int slotc_joint_dev(int s) { return perm_dev<PERMC>(s); }
 
 // The opt-in to > 64 KiB of dynamic LDS is per (kernel, device): set once per device, from any host
 // thread (pg_render_frames drives one thread per device).

@@ -44,7 +44,8 @@ constexpr int NTHR_C = NWAVE_C * 64;
 constexpr int PTS_C = NWAVE_C * 32;
 using VC = f16x8;
 using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
-using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C>;    // record variant: no view-direction segment
+// record variant: no view-direction segment; the joint-pair chunks of both x segments can be left out of a pass (Stream MASK_NX)
+using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR>;
 #ifndef PG_NSC
 #define PG_NSC 4
 #endif
@@ -55,7 +56,7 @@ static_assert(LDS_TOTAL_C <= 160 * 1024, "LDS budget of one CU");
 // table, two (a, b) buffers (this pass / the next) and the Y records of the pass's <= MAXR_CR rays
 constexpr int LDSC_BIAS = PG_RING_SLOTS * CHUNK_BYTES;
 constexpr int LDSC_CUT = LDSC_BIAS + BTC_COUNT * 32 * 4;
-constexpr int LDSC_AB = LDSC_CUT + 48 * 4;
+constexpr int LDSC_AB = LDSC_CUT + 72 * 4;          // (cut: 72 floats by joint slot -- both embedders' constants, far^2)
 constexpr int LDSC_Y = LDSC_AB + 2 * LDS_ABC_BYTES;
 constexpr int LDS_TOTAL_CR = LDSC_Y + MAXR_CR * RECC_Y_BYTES;
 static_assert(LDSC_BIAS % 16 == 0 && LDSC_CUT % 16 == 0 && LDSC_AB % 16 == 0 && LDSC_Y % 16 == 0, "LDS alignment");
@@ -370,6 +371,82 @@ __device__ __forceinline__ void x_segment_c(f32x16* acc, ST& st, const float* ab
     }
 }
 
+// Record variant: the XC sequence of pg_layout.h (per joint slot jj of the lane half two units of cutoff-weighted values
+// = one chunk per joint PAIR, then six units of directions).  `wmask` bit jj (wave-uniform): the pair is out of cutoff
+// range of all 32 points of the wave -- every value of its two units is below 6e-8 (pg_eval16r.hip x_segment16) --
+// so the wave only keeps the ring going for that chunk.  `gmask` bit jj (workgroup-uniform): out of range of the
+// whole pass; the chunk is not in the pass's chunk sequence (Stream MASK_NX).
+template <int NO, int TP, typename ST, typename HK>
+__device__ __forceinline__ void mma_row_cr(f32x16* acc, PairPipe<NSC>& p, ST& st, int uu, const FragC& b, bool& hooked, const HK& hook) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int P = uu * NO + o;
+        pair_begin<TP>(p, st, P);
+        if (o == 0 && !hooked) { hook(); hooked = true; }       // (behind the segment's first chunk entry)
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(b.x1), acc[o], 0, 0, 0);
+        pair_mid<TP>(p, st, P);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(b.x2), acc[o], 0, 0, 0);
+    }
+}
+
+template <typename ST, typename HK>
+__device__ __forceinline__ void x_segment_cr(f32x16* acc, ST& st, const float* ab, float z, const float* cutb,
+                                             float tl, float s129, int wmask, int gmask, const HK& hook) {
+    PairPipe<NSC> p;
+    constexpr int T = XUC * NT;
+    bool hooked = false;                    // wave-uniform
+    auto local = [&](int jj, float& qx, float& qy, float& qz) {
+        const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
+        qx = fmaf(z, hi.x, lo.x); qy = fmaf(z, hi.y, lo.y); qz = fmaf(z, hi.z, lo.z);
+    };
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < JH; ++jj) {
+        if ((gmask >> jj) & 1) continue;
+        if ((wmask >> jj) & 1) {
+            st.enter_split();
+            if (!hooked) { hook(); hooked = true; }
+#pragma unroll
+            for (int i = 0; i < ST::PER; ++i) piece_c(p, st, i);
+            continue;
+        }
+        float x[18], qx, qy, qz;
+        local(jj, qx, qy, qz);
+        joint_values_c(qx, qy, qz, tl, cutb[jj], x);
+        x[15] = 0.0f;                       // (the directions x[15..17] have units of their own)
+        const FragC f0 = frag_of(x, s129), f1 = frag_of(x + 8, s129);
+        mma_row_cr<NT, T>(acc, p, st, 2 * jj, f0, hooked, hook);
+        mma_row_cr<NT, T>(acc, p, st, 2 * jj + 1, f1, hooked, hook);
+    }
+    // r = q / max(|q|, 1e-12) of every joint slot (not cutoff-weighted): six units of two slots each
+#pragma clang loop unroll(full)
+    for (int pr = 0; pr < JH / 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float qx, qy, qz;
+            local(2 * pr + k, qx, qy, qz);
+            const float rinv = __builtin_amdgcn_rsqf(fmaxf(qx * qx + qy * qy + qz * qz, 1e-24f));
+            v[3 * k] = qx * rinv; v[3 * k + 1] = qy * rinv; v[3 * k + 2] = qz * rinv;
+        }
+        v[6] = v[7] = 0.0f;
+        const FragC f = frag_of(v, s129);
+        mma_row_cr<NT, T>(acc, p, st, XVC + pr, f, hooked, hook);
+    }
+}
+
+// joint pairs out of cutoff range of EVERY point of a pass, from the per-ray records (AB[ray][slot].w = squared distance
+// of the ray's sampled segment from the joint, pg_rayrec.hip): one ballot per joint slot over the two lane halves'
+// joints x the rays of the pass (lane = ray; lanes past the last ray repeat it).  The same in every wave.
+__device__ __forceinline__ int pass_far_mask_c(const uint8_t* ab, int nrm1, const float* far2h, int h, int pt) {
+    const float* row = opaque_ptr(reinterpret_cast<const float*>(ab + min(pt, nrm1) * REC_AB_BYTES) + JH * h * 8 + 3);
+    int m = 0;
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj)
+        if (__builtin_amdgcn_ballot_w64(row[jj * 8] < far2h[jj]) == 0ull) m |= 1 << jj;
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
 // Per-ray LDS slots of this kernel (pg_layout.h SLOTC_*), one thread per (ray, joint):
 //   AB[j] = (a = R_j o + t_j, b = R_j d)                       (core/encoders.py:8-37)
 //   DTAB: e = normalize(b) per joint, rows (e, sin e, cos e, ..., sin 8e | cos 8e) in D-sequence order
@@ -460,10 +537,13 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     }
     // cutoff table with the sigmoid constants folded in (cutoff_weight_fast)
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
-    if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    if (REC) {      // by joint SLOT (pg_layout.h slotc_joint), + the squared distance beyond which a cutoff weight is below 2^-24
+        if (tid < 48) cut[tid] = -a.cutoff[(tid < J ? 0 : J) + slotc_joint_dev(tid < J ? tid : tid - J)] * (tid < J ? tlv : tld);
+        else if (tid < 72) { const float far = a.cutoff[slotc_joint_dev(tid - 48)] + 24.0f / tlv; cut[tid] = far * far; }
+    } else if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
     float s129 = (float)COMP_S;
     asm volatile("" : "+s"(s129));              // one SGPR for the whole kernel, not a literal per use
-    st.start();
+    if (!REC) st.start();
 
     // record variant: ray bookkeeping without a division per pass (a 64-bit divide is ~150 VALU instructions and
     // nothing overlaps them with one wave per SIMD): the pass's first point is sample `off0` of ray `r0`, and both
@@ -481,6 +561,20 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
             dma_piece_c(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSC_AB + wave * 1024, lane16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
+    }
+    // record variant: joint pairs no point of a pass is in range of.  The first pass's mask here (the weight ring starts
+    // with it), every later pass learns its own a pass ahead, from the (a, b) records of its rays.
+    auto rays_of_pass = [&](long long p0_, int off0_) {         // index of the pass's last ray among its (<= 3) rays
+        const int last_ = (int)max(0ll, min((long long)PTS_C - 1, a.n_points - 1 - p0_));
+        const int t_ = off0_ + last_;
+        return (t_ >= a.S) + (t_ >= 2 * a.S);
+    };
+    int gmask = 0;
+    if (REC) {
+#if !defined(PG_NO_FAR_SKIP)
+        gmask = pass_far_mask_c(smem + LDSC_AB, rays_of_pass(p0, off0), cut + 2 * J + JH * h, h, pt);
+#endif
+        st.start((uint32_t)gmask);
     }
     // record variant: the depth of the next pass's point, fetched a pass ahead (unconditional, clamped index)
     float nx_z = 0.0f;
@@ -527,6 +621,20 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         const float* cutv = opaque_ptr(cut + JH * h);
         const float* cutd = opaque_ptr(cut + J + JH * h);
         const float zz = REC ? nx_z : a.z[gpc];
+        int wmask = 0;
+        if (REC) {      // joint pairs out of cutoff range of the wave's 32 points (x_segment_cr)
+#if !defined(PG_NO_FAR_SKIP)
+            const float* far2 = opaque_ptr(cut + 2 * J + JH * h);
+#pragma unroll
+            for (int jj = 0; jj < JH; ++jj) {
+                const float4 lo = *reinterpret_cast<const float4*>(ab + jj * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
+                const float qx = fmaf(zz, hi.x, lo.x), qy = fmaf(zz, hi.y, lo.y), qz = fmaf(zz, hi.z, lo.z);
+                if (__builtin_amdgcn_ballot_w64(qx * qx + qy * qy + qz * qz < far2[jj]) == 0ull) wmask |= 1 << jj;
+            }
+            wmask = __builtin_amdgcn_readfirstlane(wmask);
+#endif
+        }
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the (a, b)
         // buffer of the pass before may be overwritten.  The 4 waves share the 16 pieces of each of this pass's
         // MAXR_CR Y records, waves 0..2 fetch a piece of the NEXT pass's (a, b); issued before the chunk's refill
@@ -551,7 +659,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         // ---- layer 0: K = 432 generated on the fly ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + o, h);
-        x_segment_c(accA, st, ab, zz, cutv, tlv, s129, fetch_records);
+        if constexpr (REC) x_segment_cr(accA, st, ab, zz, cutv, tlv, s129, wmask, gmask, fetch_records);
+        else x_segment_c(accA, st, ab, zz, cutv, tlv, s129, fetch_records);
         if (TAPS && a.dbg && a.dbg_stage == 0 && valid) {
 #pragma unroll
             for (int o = 0; o < NT; ++o)
@@ -580,7 +689,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
         segment_c<NT, HU, true>(accB, st, srcA, s129);
         PG_STAMP(4);
-        x_segment_c(accB, st, ab, zz, cutv, tlv, s129);
+        if constexpr (REC) x_segment_cr(accB, st, ab, zz, cutv, tlv, s129, wmask, gmask, NoHook());
+        else x_segment_c(accB, st, ab, zz, cutv, tlv, s129);
         PG_STAMP(5);
         // ---- layers 6, 7 ----
 #pragma unroll
@@ -594,6 +704,15 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
             for (int i = 0; i < HSEQ; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(accB[i >> 4][i & 15], 0.0f);
         }
         PG_STAMP(6);
+        int gmask_n = 0;
+        if (REC) {      // the NEXT pass's mask, from its (a, b) records (in LDS since this pass's second chunk entry): the ring's
+                        // prefetch pointer wraps to the head of the stream within the next segments and must know it by then
+#if !defined(PG_NO_FAR_SKIP)
+            gmask_n = pass_far_mask_c(smem + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES, rays_of_pass(p0 + step, off0n),
+                                      opaque_ptr(cut + 2 * J + JH * h), h, pt);
+#endif
+            st.nx_mask = (uint32_t)gmask_n;
+        }
         // ---- sigma head and the view layer's trunk part in one segment of 1 + 4 out tiles: feature_linear
         // has no activation and is folded into the view weights on the host (NetTensors::fold) ----
         f32x16 av[NTV + 1];
@@ -682,7 +801,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         if (valid && h == 0)
             *reinterpret_cast<float4*>(a.raw + gp * 4) = make_float4(accr[0], accr[1], accr[2], sigma);
 #endif
-        if (REC) { abuf ^= 1; r0 = r0n; off0 = off0n; }
+        if (REC) { abuf ^= 1; r0 = r0n; off0 = off0n; gmask = gmask_n; }
         p0 += step;
 #if !defined(PG_STAMPS_RGB)
         PG_STAMP(9);

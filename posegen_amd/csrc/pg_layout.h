@@ -216,11 +216,32 @@ constexpr int MAXR_CR = 3;
 constexpr int LDS_ABC_BYTES = 3072;               // one AB buffer in LDS: MAXR_CR x 768 = 2304 -> 3 DMA pieces of 1 KiB
 constexpr int VYC_K = 28;                         // 27 view values per joint (16 of the frame code), padded
 constexpr int VYC_FLOATS = (J + 1) * VYC_K * VW;
-// joint whose weight is value e of k-unit u in lane half h of the second-stage B operand (-1 = zero)
-PG_HD constexpr int vyc_slot_joint(int u, int h, int e, bool fc) {
+// SLOT (slotc_joint below; JC = the frame code) whose weight is value e of k-unit u in lane half h of the second-stage
+// B operand (-1 = zero)
+PG_HD constexpr int vyc_slot(int u, int h, int e, bool fc) {
     if (u == 0) return JH * h + e;
     if (e < JH - 8) return JH * h + 8 + e;
     return (fc && h == 0 && e == JH - 8) ? JC : -1;
+}
+// ---- density input of the compensated kernel's RECORD variant (pg_evalc.hip REC): like the 16x16x32 kernel's X16
+// sequence, with the TWO lane halves' joints of a unit forming one limb segment, so that a wave (and a pass) can leave
+// out the units of a joint pair that is out of cutoff range (pg_eval16r.hip explains the test).  Slot s = 12 h + jj of
+// lane half h holds joint PERMC[s]; per slot two units of cutoff-weighted values (one chunk of 16 unit pairs per joint
+// pair), then six units of directions (two slots each).  The (a, b) records, the cutoff tables and the Y records of
+// this variant are in slot order too.
+constexpr int PERMC[24] = {1, 7, 2, 8, 16, 20, 17, 21, 0, 6, 12, 13,   4, 10, 5, 11, 18, 22, 19, 23, 3, 9, 15, 14};
+PG_HD constexpr int slotc_joint(int s) { return PERMC[s]; }
+constexpr int XVC = 2 * JH;             // 24 units of cutoff-weighted values
+constexpr int XUC = XVC + JH / 2;       // + 6 units of directions = 30
+PG_HD constexpr int xseqc_channel(int i, int h) {
+    int u = i / 8, e = i % 8;
+    if (u < XVC) {
+        int q = 8 * (u % 2) + e;
+        if (q >= ROWS_V) return -1;
+        return q * J + slotc_joint(JH * h + u / 2);
+    }
+    if (e >= 6) return -1;
+    return CH_V + 3 * slotc_joint(JH * h + 2 * (u - XVC) + e / 3) + e % 3;
 }
 static_assert(MAXR_CR * REC_AB_BYTES <= LDS_ABC_BYTES && LDS_ABC_BYTES / REC_AB_BYTES + 1 <= REC_PAD_RAYS && MAXR_CR <= REC_PAD_RAYS,
               "record fetches stay inside the padded arrays");

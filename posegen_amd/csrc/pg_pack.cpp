@@ -51,6 +51,7 @@ static int seq_channel(int seq, int i, int h) {
         case SEQ_H: return hseq_channel(i, h);
         case SEQ_D: return dseq_channel(i, h);
         case SEQ_CODE: return 8 * h + i;
+        case SEQ_XC: return xseqc_channel(i, h);
     }
     return -1;
 }
@@ -99,10 +100,11 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
     if (shape == SHAPE_C) {         // compensated fp16 kernel (pg_evalc.hip): k-major everywhere, direct view layer
-        s.push_back({MAT_L0, NT, true, {{SEQ_X, XSEQ, 0}}});
+        const InUnits xin = rec ? InUnits{SEQ_XC, XUC * 8, 0} : InUnits{SEQ_X, XSEQ, 0};     // record variant: limb-wise x sequence
+        s.push_back({MAT_L0, NT, true, {xin}});
         for (int l = 1; l <= 4; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
         s.push_back({MAT_L0 + 5, NT, true, {hid(CH_X)}});
-        s.push_back({MAT_L0 + 5, NT, true, {{SEQ_X, XSEQ, 0}}});
+        s.push_back({MAT_L0 + 5, NT, true, {xin}});
         for (int l = 6; l <= 7; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
         s.push_back({MAT_ALPHA_VIEWF, NTV + 1, true, {hid(0)}});
         if (!rec) {                 // (record variant: the view directions arrive as per-ray Y records)
@@ -203,12 +205,13 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
 }
 
 void pack_vyc(const NetTensors& t, bool fc, std::vector<float>& out) {
+    // row block s = joint SLOT s of the record variant (slotc_joint), then the frame code
     out.assign((size_t)VYC_FLOATS, 0.f);
-    for (int j = 0; j < J + (fc ? 1 : 0); ++j)
+    for (int sl = 0; sl < J + (fc ? 1 : 0); ++sl)
         for (int k = 0; k < VYC_K; ++k) {
-            const int ch = vd_channel(j, k);
+            const int ch = vd_channel(sl < J ? slotc_joint(sl) : JC, k);
             if (ch < 0) continue;
-            for (int o = 0; o < VW; ++o) out[((size_t)j * VYC_K + k) * VW + o] = t.w(MAT_VIEW, o, W + ch);
+            for (int o = 0; o < VW; ++o) out[((size_t)sl * VYC_K + k) * VW + o] = t.w(MAT_VIEW, o, W + ch);
         }
 }
 

@@ -14,7 +14,7 @@
 namespace pgp {
 using namespace pgl;
 
-enum Seq { SEQ_X = 0, SEQ_H = 1, SEQ_D = 2, SEQ_CODE = 3 };
+enum Seq { SEQ_X = 0, SEQ_H = 1, SEQ_D = 2, SEQ_CODE = 3, SEQ_XC = 4 /* record variant of the compensated kernel */ };
 enum Mat { MAT_L0 = 0, /* .. MAT_L7 = 7 */ MAT_FEAT = 8, MAT_ALPHA = 9, MAT_VIEW = 10, MAT_RGB = 11,
            MAT_FEAT_ALPHA = 12 /* tiles 0..7 feature_linear, tile 8 row 0 alpha_linear */,
            MAT_ALPHA_VIEWF = 13 /* tile 0 row 0 alpha_linear, tiles 1..4 W_view[:, :256] W_feature */,
@@ -115,9 +115,14 @@ static_assert(cdiv(DU * NTV, PPC) == CH_VD, "view segment must take the same chu
 constexpr int MFMA_PER_GROUP(bool fc) {
     return 2 * (2 * XU * NT + 7 * HU * NT + HU * (NTV + 1) + (DU + (fc ? 1 : 0)) * NTV + HU / 2);
 }
-// record variant (>= 64 samples per ray): no view-direction segment, its second stage is 2 k-units x NTV tiles per ray
-constexpr int NCHUNK_R = NCHUNK - CH_VD;
-constexpr int MFMA_PER_GROUP_R = 2 * (2 * XU * NT + 7 * HU * NT + HU * (NTV + 1) + HU / 2) + 2 * 2 * NTV;
+// record variant (>= 64 samples per ray): no view-direction segment, its second stage is 2 k-units x NTV tiles per ray;
+// the density input in the XC sequence (pg_layout.h): one chunk per joint pair (12), then the directions (3 chunks)
+constexpr int CH_L0XR = cdiv(XUC * NT, PPC);            // 15
+constexpr int NCHUNK_R = 2 * CH_L0XR + 7 * CH_HID + CH_AV + 1;
+constexpr int C_L5XR = CH_L0XR + 5 * CH_HID;            // 55: first chunk of the skip layer's x part
+constexpr int NPAIRJ = JH;                              // joint-pair chunks at the head of both x segments
+static_assert(2 * NT == PPC, "a joint pair's two unit rows are exactly one chunk");
+constexpr int MFMA_PER_GROUP_R = 2 * (2 * XUC * NT + 7 * HU * NT + HU * (NTV + 1) + HU / 2) + 2 * 2 * NTV;
 }  // namespace C
 
 }  // namespace pgp

@@ -250,8 +250,8 @@ __global__ __launch_bounds__(RECC_THREADS, 1) void ray_records_c_kernel(const Re
             const bool live = r0 + rr < a.n_rays;
             const long long ray = live ? r0 + rr : a.n_rays - 1;
             float* tv = tl + rr * RECC_TSTRIDE + j * VYC_K;
-            if (j < J) {
-                const float4* sk = reinterpret_cast<const float4*>(a.skts + ray * a.pose_stride + j * 16);
+            if (j < J) {        // (j = joint SLOT of the compensated kernel's record variant: joint slotc_joint(j), pg_layout.h)
+                const float4* sk = reinterpret_cast<const float4*>(a.skts + ray * a.pose_stride + slotc_joint_dev(j) * 16);
                 const float4 ra = sk[0], rb = sk[1], rc = sk[2];
                 const float* ry = a.rays + ray * 11;
                 const float ox = ry[0], oy = ry[1], oz = ry[2], dx = ry[3], dy = ry[4], dz = ry[5];

@@ -121,6 +121,20 @@ def vd_channel(j, k):
 
 
 PERM16 = [1, 2, 16, 17, 0, 12, 4, 5, 18, 19, 3, 13, 7, 8, 20, 21, 6, 14, 10, 11, 22, 23, 9, 15]     # pg_layout.h: slot -> joint
+PERMC = [1, 7, 2, 8, 16, 20, 17, 21, 0, 6, 12, 13, 4, 10, 5, 11, 18, 22, 19, 23, 3, 9, 15, 14]       # ... of the compensated record variant
+XVC, XUC = 24, 30
+
+
+def xseqc_channel(i, h):
+    """pg_layout.h xseqc_channel: units 2 jj, 2 jj + 1 = the 15 cutoff-weighted values of joint slot jj of lane half h
+    (+ a pad), units 24 + p = the directions of slots 2 p, 2 p + 1 (+ two pads)"""
+    u, e = divmod(i, 8)
+    if u < XVC:
+        q = 8 * (u % 2) + e
+        return q * J + PERMC[JH * h + u // 2] if q < 15 else -1
+    if e >= 6:
+        return -1
+    return 360 + 3 * PERMC[JH * h + 2 * (u - XVC) + e // 3] + e % 3
 
 
 def vy_joint(w, e, fc):
@@ -388,12 +402,14 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
         return pair_vals(hseq_channel, len(tiles) * 16, act.T)
 
     tiles_of = lambda t0, n: [bias_tile(t0 + o) for o in range(n)]
-    xs = pair_vals(xseq_channel, XSEQ, x[:, :432])
-    tiles = segment(NT, [(xs, XSEQ)], tiles_of(0, NT))
+    # record variant: the XC sequence (one chunk per joint pair, then the directions; joint slots PERMC) -- pg_layout.h
+    xfn, xn = (xseqc_channel, XUC * 8) if rec is not None else (xseq_channel, XSEQ)
+    xs = pair_vals(xfn, xn, x[:, :432])
+    tiles = segment(NT, [(xs, xn)], tiles_of(0, NT))
     for l in range(1, 5):
         tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
     tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(5 * NT, NT))
-    tiles = segment(NT, [(xs, XSEQ)], tiles)
+    tiles = segment(NT, [(xs, xn)], tiles)
     for l in (6, 7):
         tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
     av = segment(NTV + 1, [(hidden(tiles), HSEQ)], [bias_tile(BT_ALPHA)] + tiles_of(BT_VIEWF, NTV))
@@ -411,10 +427,11 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
         fc = bool(cfg.framecode_ch)
         wy = vyc.view(np.float32).reshape(J + 1, 28, VW)
         y = np.zeros((J + 1, VW), dtype=np.float32)
-        for j in range(J + (1 if fc else 0)):
+        for sl in range(J + (1 if fc else 0)):                    # weight blocks are in SLOT order (pack_vyc), y by joint
+            j = PERMC[sl] if sl < J else J
             acc = np.zeros(VW, dtype=np.float32)
             for k in range(28):
-                acc = np.float32(wy[j, k] * np.float32(tray[j, k]) + acc) if k < 27 or j == J else acc
+                acc = np.float32(wy[sl, k] * np.float32(tray[j, k]) + acc) if k < 27 or j == J else acc
             y[j] = acc
         ys = (y * np.float32(1.0 / S)).astype(np.float32)
         y1 = h16(ys)
@@ -427,9 +444,10 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
             wv_ = np.zeros((2, 8, 32), dtype=np.float32)           # [h, e, pt]
             for h in range(2):
                 for e in range(8):
-                    j = vy_slot_joint(u, h, e, fc)
-                    if j < 0:
+                    sl = vy_slot_joint(u, h, e, fc)               # a SLOT of the record variant
+                    if sl < 0:
                         continue
+                    j = PERMC[sl] if sl < J else J
                     a0[:, h, e], a1[:, h, e] = p0[j], p1[j]
                     wv_[h, e] = wpt[:, j] if j < J else 1.0
             x1 = h16(wv_)
