@@ -251,7 +251,7 @@ class _DryCaster:
     module = property(lambda self: self)
 
 
-def train_step_rate(dev, n_rand=4096, steps=5, warmup=2):
+def train_step_rate(dev, n_rand=4096, steps=5, warmup=2, precision="fp32"):
     """SURVEY 8(f) rank 4, the training step on the HIP path (posegen_amd.train.TrainableRayCaster): N_rand rays of the
     benchmark frame (run_nerf.py:211 default 32*32*4), 64 + 16 samples, jitter + density noise, the Trainer's MSE loss
     on both maps (trainer.py:321-383), loss.backward(), Adam -- time per step and the fp32 GEMM rate it implies."""
@@ -260,14 +260,14 @@ def train_step_rate(dev, n_rand=4096, steps=5, warmup=2):
     from posegen_amd.raycaster import HipRayCaster
     from posegen_amd.train import TrainableRayCaster
     cfg = surreal_config()
-    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=dev, precision="fp32")
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=dev, precision=precision)
     m = TrainableRayCaster(c)
     m.train()
     rb, skts, cyl, *_ = full_frame_rays(512, 512, dev)
     sel = torch.linspace(0, rb.shape[0] - 1, n_rand, device=dev).long()
     rb = rb[sel].contiguous()
     target = torch.rand(n_rand, 3, device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.999))
 
     def step():
         opt.zero_grad()
@@ -289,11 +289,14 @@ def train_step_rate(dev, n_rand=4096, steps=5, warmup=2):
     pts = n_rand * (2 * cfg.n_samples + cfg.n_importance)
     flop = 3.0 * pts * cfg.flops_per_point()
     m.renderer.close()
+    peak = PEAK_TFLOPS["fp32" if precision == "fp32" else "bf16"]
     return {"n_rand": n_rand, "ms_per_step": ms, "rays_per_s": n_rand / (ms * 1e-3), "points_per_step": pts,
-            "gemm_flop_per_step": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": PEAK_TFLOPS["fp32"],
-            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], "dtype": "f32", "loss": float(loss.detach()),
-            "what": "forward with a tape + MSE loss + loss.backward() + Adam on the whole step's wall clock, fp32 "
-                    "(v_mfma_f32_32x32x2_f32 GEMMs), surreal 64+16, perturb=1, raw_noise_std=1; FLOPs = 3 x the forward MLP "
+            "gemm_flop_per_step": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": peak,
+            "frac": flop / (ms * 1e-3) / 1e12 / peak, "dtype": "f32" if precision == "fp32" else "bf16", "loss": float(loss.detach()),
+            "what": "forward with a tape + MSE loss + loss.backward() + Adam on the whole step's wall clock, "
+                    + ("fp32 (v_mfma_f32_32x32x2_f32 GEMMs)" if precision == "fp32" else
+                       "16-bit training mode (bf16 operands in the large GEMMs on v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage)")
+                    + ", surreal 64+16, perturb=1, raw_noise_std=1; FLOPs = 3 x the forward MLP "
                     "FLOPs of the step's points (forward, dX and dW GEMMs); embedding and compositing not counted"}
 
 
@@ -426,15 +429,23 @@ def main():
             strong_step()
         sync()
         sdt = max_over_ranks(time.perf_counter() - t1) / reps
+        # the serial host part on an IDLE device (in the back-to-back loop above the boxes' copy-back also waits for the
+        # previous step's frames): device idle before each of three more steps
+        strong_state["host_pre_launch_ms"].clear()
+        for _ in range(3):
+            sync()
+            strong_step()
+        sync()
         pre = sorted(strong_state["host_pre_launch_ms"])
         host_serial = max_over_ranks(pre[len(pre) // 2] if pre else 0.0)
         from posegen_amd.dist import plan_tasks
         side = {"scaling": "strong", "frames_per_step": a.frames, "valid_rays_per_step": strong_state["valid"],
                 "rays_per_s": strong_state["valid"] / sdt, "ms_per_step": sdt * 1e3, "ms_per_frame": sdt * 1e3 / a.frames,
                 "n_gpus": world,
-                # host work of a step that no GPU overlaps (call entry -> first render launch: device boxes with their
-                # 16-byte-per-frame copy back, the plan, the pose upload): what every rank repeats, i.e. the serial
-                # term of the 8-GPU bound T1 / (T1 / 8 + host) of DESIGN.md 4; median over the steps, max over ranks
+                # host work of a step that no GPU overlaps (call entry -> first render launch on an idle device: device
+                # boxes with their 16-byte-per-frame copy back, the plan, the pose upload): what every rank repeats,
+                # i.e. the serial term of the 8-GPU bound T1 / (T1 / 8 + host) of DESIGN.md 4; median of three steps,
+                # max over ranks
                 "host_serial_ms_per_step": host_serial, "host_enqueue_ms_per_step": strong_state.get("host_ms", 0.0),
                 "what": f"dist.render_frames_distributed: {a.frames} poses at {H}x{W}, reference bounding-cylinder cull, "
                         f"nanmean groups of {cfg.chunk} rays planned over {world} rank(s), one all-gather of the packed maps "
@@ -637,7 +648,8 @@ def main():
             "rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / peak, "avg_launch_ms": kms,
             "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
         cast4.renderer.close()
-        result["train_step"] = train_step_rate(dev)
+        result["train_step"] = train_step_rate(dev, precision="bf16")
+        result["train_step"]["fp32"] = train_step_rate(dev, precision="fp32")
         if not a.no_cpu_baseline:
             result["train_step"]["cpu_baseline"] = cpu_train_baseline(rb_cpu, skts_cpu, cyl_cpu, cfg, model)
         if not a.no_cpu_baseline:   # BASELINE config 1: 128x128, 32 coarse (+16) samples per ray

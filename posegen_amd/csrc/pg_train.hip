@@ -301,6 +301,127 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
     if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
 }
 
+// ---- the same GEMM with bf16 operands (fp32 in HBM, rounded on the way into LDS; fp32 accumulate): the 16-bit training
+// mode.  128 x 128 x 32 tiles on v_mfma_f32_32x32x16_bf16, LDS rows [row][32 k + 8 pad] bf16 (80-byte pitch: the 16-byte
+// fragment reads of a 16-lane group fall on 16 different bank quads), k-contiguous operands stored 4 k at a time,
+// k-strided ones as (k, k + 1) pairs.
+constexpr int BK = 32, BPITCH = BK + 8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8t;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool KCONT>
+__device__ __forceinline__ void btile_fetch(float4 (&v)[4], const float* __restrict__ P, long long s_row, long long s_k,
+                                            int row0, int rows, int kb, int k1, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KCONT) {            // 4 consecutive k of one row
+            const int idx = t + 256 * i, r = idx >> 3, k = kb + (idx & 7) * 4;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)(row0 + r) * s_row + k);
+        } else {                // 4 consecutive rows of k = 2 kp and (i odd) 2 kp + 1
+            const int kp = (t >> 5) + 8 * (i >> 1), k = kb + 2 * kp + (i & 1), r = (t & 31) * 4;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)k * s_k + row0 + r);
+        }
+    }
+}
+
+template <bool KCONT>
+__device__ __forceinline__ void btile_store(unsigned short (*T)[BPITCH], const float4 (&v)[4], int t) {
+    if (KCONT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, r = idx >> 3, kq = (idx & 7) * 4;
+            *reinterpret_cast<uint2*>(&T[r][kq]) = make_uint2(pack_bf16(v[i].x, v[i].y), pack_bf16(v[i].z, v[i].w));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kp = (t >> 5) + 8 * i, r = (t & 31) * 4;
+            const float4 a = v[2 * i], b = v[2 * i + 1];
+            *reinterpret_cast<unsigned*>(&T[r][2 * kp]) = pack_bf16(a.x, b.x);
+            *reinterpret_cast<unsigned*>(&T[r + 1][2 * kp]) = pack_bf16(a.y, b.y);
+            *reinterpret_cast<unsigned*>(&T[r + 2][2 * kp]) = pack_bf16(a.z, b.z);
+            *reinterpret_cast<unsigned*>(&T[r + 3][2 * kp]) = pack_bf16(a.w, b.w);
+        }
+    }
+}
+
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(256) void bgemm128_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
+                                                       const float* __restrict__ B, long long sbk, long long sbn,
+                                                       float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                       const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
+                                                       float* __restrict__ part, float* __restrict__ rs_part) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[TB][BPITCH], Bs[TB][BPITCH];
+    float rs = 0.0f;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6, wm = (wv >> 1) * 64, wn = (wv & 1) * 64, li = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+    const int nz = gridDim.z;
+    const int kper = ((K + nz - 1) / nz + BK - 1) / BK * BK;
+    const int k0 = blockIdx.z * kper, k1 = min(K, k0 + kper);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float4 va[4], vb[4];
+    btile_fetch<A_KCONT>(va, A, sam, sak, m0, M, k0, k1, t);
+    btile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, k0, k1, t);
+    for (int kb = k0; kb < k1; kb += BK) {
+        btile_store<A_KCONT>(As, va, t);
+        btile_store<B_KCONT>(Bs, vb, t);
+        __syncthreads();
+        btile_fetch<A_KCONT>(va, A, sam, sak, m0, M, kb + BK, k1, t);       // (all zeros past the end)
+        btile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, kb + BK, k1, t);
+        if (!A_KCONT && rowsum && (unsigned)((kb - k0) / BK) % gridDim.x == blockIdx.x && t < TB) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += __builtin_bit_cast(float, (unsigned)As[t][kk] << 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8t a0 = *reinterpret_cast<const bf16x8t*>(&As[wm + li][16 * ks + 8 * kh]);
+            const bf16x8t a1 = *reinterpret_cast<const bf16x8t*>(&As[wm + 32 + li][16 * ks + 8 * kh]);
+            const bf16x8t b0 = *reinterpret_cast<const bf16x8t*>(&Bs[wn + li][16 * ks + 8 * kh]);
+            const bf16x8t b1 = *reinterpret_cast<const bf16x8t*>(&Bs[wn + 32 + li][16 * ks + 8 * kh]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 32 * j + li;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + rho(r, kh);
+                if (m >= M) continue;
+                float* c = C + (long long)m * ldc + n;
+                float v = acc[i][j][r];
+                if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
+                if (flags & GEMM_ACC) v += *c;
+                v += bv;
+                if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
+                if (mask && !(mask[(long long)m * ldm + n] > 0.0f)) v = 0.0f;
+                *c = v;
+            }
+    }
+    if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
+}
+
 // out[i (row-major M x N with leading dimension ldo)] = sum over the nz slices of part[z][M][N], in slice order
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nz, int M, int N,
                                                           float* __restrict__ out, long long ldo) {
@@ -438,6 +559,7 @@ struct Tape {
     Pass pass[2];
     pg_net_params params[2];
     bool has_fine = false;
+    bool bf16 = false;          // 16-bit training mode (handle precision PG_PREC_BF16): bf16 operands in the large GEMMs
 };
 
 constexpr size_t PART_FLOATS = 20u << 20;        // split-K scratch: slices x M x N of the largest weight gradient (80 MB)
@@ -476,10 +598,18 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
         if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
-        if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, true>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
-        else if (a_kcont) hipLaunchKernelGGL((sgemm128_kernel<true, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
-        else hipLaunchKernelGGL((sgemm128_kernel<false, false>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part);
-        PG_LAUNCH_CHECK(h, "sgemm128");
+#define PG_GEMM128(KERNEL, AK, BK_) hipLaunchKernelGGL((KERNEL<AK, BK_>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part)
+        if (t.bf16) {
+            if (a_kcont && b_kcont) PG_GEMM128(bgemm128_kernel, true, true);
+            else if (a_kcont) PG_GEMM128(bgemm128_kernel, true, false);
+            else PG_GEMM128(bgemm128_kernel, false, false);
+        } else {
+            if (a_kcont && b_kcont) PG_GEMM128(sgemm128_kernel, true, true);
+            else if (a_kcont) PG_GEMM128(sgemm128_kernel, true, false);
+            else PG_GEMM128(sgemm128_kernel, false, false);
+        }
+#undef PG_GEMM128
+        PG_LAUNCH_CHECK(h, "gemm128");
         if (ksplit > 1) { reduce(t.part, ksplit, M, N, C, ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
         if (rowsum && !a_kcont) { reduce(t.rs_part, ksplit * (int)g.x, M, 1, rowsum, 1); PG_LAUNCH_CHECK(h, "row-sum reduction"); }
         return PG_OK;
@@ -525,7 +655,9 @@ int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
                  float* dW, long long ldw, float* db = nullptr) {      // db[out] += column sums of dY (the bias gradient, fused)
     const int tb = (out >= 64 && in >= 64) ? TB : GB;            // the tile gemm() will pick
     const int tiles = ((out + tb - 1) / tb) * ((in + tb - 1) / tb);
-    int ksplit = (int)std::max<long long>(1, std::min<long long>(1024 / std::max(tiles, 1), (P + 1023) / 1024));
+    // about one workgroup per CU (the GEMM streams dY and X once whatever the split): every slice costs a tile of partial
+    // sums written and read again by the reduction
+    int ksplit = (int)std::max<long long>(1, std::min<long long>(256 / std::max(tiles, 1), (P + 2047) / 2048));
     return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2), nullptr, 0, db);
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
@@ -682,6 +814,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     uint8_t* q = t.buf;
     auto take = [&](size_t b) { float* r = reinterpret_cast<float*>(q); q += al(b); return r; };
     t.n = n; t.S = S; t.N = N; t.fc = fc; t.has_fine = N > 0;
+    t.bf16 = h->cfg.precision == PG_PREC_BF16;
     t.rays = take((size_t)n * 44);
     t.cams = cams ? take((size_t)n * 4) : (take((size_t)n * 4), nullptr);
     float* nf = take((size_t)n * 8);
