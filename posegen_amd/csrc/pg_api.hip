@@ -20,7 +20,7 @@
 
 extern "C" {
 int pg_launch_eval16(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
-int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream);
+int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int onchip, int grid, void* stream);
 int pg_launch_ray_records(const pgd::RecArgs* a, int fp16, int framecode, int n_cu, void* stream);
 int pg_eval16_points_per_pass(void);
 int pg_eval16_wgs_per_cu(void);
@@ -186,6 +186,35 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     return PG_OK;
 }
 
+// the on-chip variant of the 16x16x32 kernel (one pose per launch, no frame codes): its stream; the bias table is shared
+int ensure_stream_ro(pg_handle* h, int which, int prec) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (ns.d_stream_ro[prec] && ns.d_bias_s) return PG_OK;
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    PG_HIP(h, hipSetDevice(h->device));
+    if (!ns.d_stream_ro[prec]) {
+        std::vector<uint8_t> packed;
+        const int rc = pgpack::pack_stream_r(t, prec, packed, true);
+        if (rc != 0) return pg_fail(h, PG_EINVAL, "on-chip 16x16x32 weight stream packing failed (%d) for precision %d", rc, prec);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_ro[prec]), packed.size()));
+        PG_HIP(h, hipMemcpy(ns.d_stream_ro[prec], packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    if (!ns.d_bias_s) {
+        std::vector<float> b;
+        pgpack::pack_bias_s(t, b);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias_s), b.size() * sizeof(float)));
+        PG_HIP(h, hipMemcpy(ns.d_bias_s, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return PG_OK;
+}
+
+// ... which runs when the launch has one pose and no frame codes (POSEGEN_ONCHIP=0 forces the record variant: A/B, tests)
+bool use_onchip(bool fc, long long pose_stride) {
+    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_ONCHIP"); return !(e && e[0] == '0'); }();
+    return allowed && !fc && pose_stride == 0;
+}
+
 int ensure_stream_cr(pg_handle* h, int which) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -226,7 +255,8 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
     auto one = [&](int prec) {
         if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) {       // + the direct kernel's stream (short rays, points)
-            const int rc = ensure_stream_r(h, which, prec);
+            int rc = ensure_stream_r(h, which, prec);
+            if (!rc && h->cfg.framecode_ch == 0) rc = ensure_stream_ro(h, which, prec);
             return rc ? rc : ensure_stream(h, which, prec, false);
         }
         if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) {     // + the direct form's stream (32 <= S < 64)
@@ -270,21 +300,23 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool compk = !pnoise && use_comp_kernel(prec, S, points != nullptr);
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
-    const bool recs = sa && fact;                                 // per-ray records + the 16x16x32 kernel
+    const bool fc = h->cfg.framecode_ch > 0;
+    const bool onchip = sa && fact && !dbg && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records
+    const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
     const bool crec = compk && use_comp_rec(S);                   // per-ray records + the record variant of pg_evalc.hip
-    int rc = recs ? ensure_stream_r(h, which, prec) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
+    int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec)
+           : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const int y_bytes = crec ? RECC_Y_BYTES : REC_Y_BYTES;
     if ((recs || crec) && (rc = ensure_rec(h, n, y_bytes))) return rc;
     NetState& ns = h->net[which];
-    const bool fc = h->cfg.framecode_ch > 0;
     if (fc && !ns.d_codes) return pg_fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = recs ? ns.d_stream_r[prec] : crec ? ns.d_stream_cr : ns.d_stream[prec][fact];
+    a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : crec ? ns.d_stream_cr : ns.d_stream[prec][fact];
     a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : nullptr;
-    a.bias = recs ? ns.d_bias_s : ns.d_bias;
+    a.bias = (recs || onchip) ? ns.d_bias_s : ns.d_bias;
     if (recs || crec) {
         a.rec_y = h->rec;
         a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes);
@@ -345,7 +377,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
         PG_HIP(h, get(e1));
         PG_HIP(h, hipEventRecord(e0, static_cast<hipStream_t>(stream)));
     }
-    int e = recs ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, grid, stream)
+    int e = (recs || onchip) ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, onchip, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
           : compk ? pg_launch_evalc(&a, fc, crec, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
@@ -499,6 +531,7 @@ void pg_destroy(pg_handle* h) {
     for (auto& pr : h->ev_aux) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (NetState& ns : h->net) {
         for (auto& p : ns.d_stream_r) if (p) (void)hipFree(p);
+        for (auto& p : ns.d_stream_ro) if (p) (void)hipFree(p);
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
@@ -545,6 +578,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     for (int p = 0; p < PG_PREC_COUNT; ++p) {
         if (ns.d_vy[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vy[p])); ns.d_vy[p] = nullptr; }
         if (ns.d_stream_r[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_r[p])); ns.d_stream_r[p] = nullptr; }
+        if (ns.d_stream_ro[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_ro[p])); ns.d_stream_ro[p] = nullptr; }
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
     if (ns.d_stream_cr) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_cr)); ns.d_stream_cr = nullptr; }
@@ -679,7 +713,7 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     std::vector<uint8_t> packed;
     const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
     const bool crec = view_fact == 2 && precision == PG_PREC_FP16C;     // record variant of pg_evalc.hip
-    const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed)
+    const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed, view_fact == 3)
                          : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed, nullptr, crec);
     if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
@@ -778,7 +812,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     const bool fact = use_fact(precision, FACT_MIN_S);
     const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
     if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
-        if (stream_bytes) *stream_bytes = (int64_t)pgp::R::NCHUNK * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
         return PG_OK;
     }

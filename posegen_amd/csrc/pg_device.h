@@ -105,10 +105,10 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // its issue cost off the critical wave of the SIMD.
 // MASK_NX > 0 (pg_eval16r.hip): chunks MASK_X0 + k and MASK_X1 + k (k < MASK_NX) of the stream hold the weights of one
 // LIMB each; chunk k of both ranges is left out of a pass's chunk sequence when bit k of the pass's mask is set (no
-// workgroup point is within cutoff range of the limb: nothing would read it).  The mask must be the same in every
+// workgroup point is within cutoff range of the limb: nothing would read it); MASK_X2 >= 0: a third such range.  The mask must be the same in every
 // wave.  `pf_mask` is the mask of the pass the prefetch pointer is in, `nx_mask` that of the pass behind it (taken
 // over when the pointer wraps to the head of the stream).
-template <int NWAVE, int NCHUNK_, int NDMA = NWAVE, int MASK_NX = 0, int MASK_X0 = 0, int MASK_X1 = 0>
+template <int NWAVE, int NCHUNK_, int NDMA = NWAVE, int MASK_NX = 0, int MASK_X0 = 0, int MASK_X1 = 0, int MASK_X2 = -1>
 struct Stream {
     static constexpr int NSLOT = PG_RING_SLOTS;
     static constexpr int DEPTH = NSLOT - 1;
@@ -131,8 +131,8 @@ struct Stream {
     __device__ __forceinline__ void skip_masked() {
         if constexpr (MASK_NX > 0) {
             const uint32_t c = next_off / CHUNK_BYTES;
-            const uint32_t k0 = c - (uint32_t)MASK_X0, k1 = c - (uint32_t)MASK_X1;
-            const uint32_t k = k0 < (uint32_t)MASK_NX ? k0 : k1;
+            const uint32_t k0 = c - (uint32_t)MASK_X0, k1 = c - (uint32_t)MASK_X1, k2 = c - (uint32_t)MASK_X2;
+            const uint32_t k = k0 < (uint32_t)MASK_NX ? k0 : (MASK_X2 >= 0 && k2 < (uint32_t)MASK_NX ? k2 : k1);
             // bits >= MASK_NX of a mask are zero: the run of set bits from k ends inside the limb range
             if (k < (uint32_t)MASK_NX) next_off += (uint32_t)__builtin_ctz(~(pf_mask >> k)) * CHUNK_BYTES;
         }

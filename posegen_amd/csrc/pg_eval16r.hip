@@ -25,6 +25,8 @@
 #ifndef PG_PIPE_H
 #define PG_PIPE_H 4           // A-pipe register sets in the hidden layers and heads: reads three units ahead (-0.3 % against two; five: the same)
 #endif
+#include <type_traits>
+
 #include "pg_eval16_common.h"
 
 // cache policy of the per-ray record fetches (streamed once; must not evict the weight stream from L2)
@@ -49,6 +51,8 @@ template <> struct Op16<f16x8> {
 };
 
 using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES, pgp::R::NLIMB, 0, pgp::R::C_L5X>;
+// on-chip variant (no per-ray records in HBM): the limb chunks of the view layer's direction weights sit behind layer 0
+using StreamRO = Stream<NWAVE, pgp::R::NCHUNK_OC, PG_DMA_WAVES, pgp::R::NLIMB, 0, pgp::R::C_L5X_OC, pgp::R::C_Y>;
 
 // LDS carve-up of this kernel (bytes)
 constexpr int LDSR_RING = 0;
@@ -59,6 +63,12 @@ constexpr int LDSR_Y = LDSR_AB + 2 * LDS_AB_BYTES;              // MAXR_F rays x
 constexpr int LDSR_TOTAL = LDSR_Y + MAXR_F * REC_Y_BYTES;
 static_assert(LDSR_BIAS % 16 == 0 && LDSR_CUT % 16 == 0 && LDSR_AB % 16 == 0 && LDSR_Y % 16 == 0, "LDS alignment");
 static_assert(LDSR_TOTAL <= 160 * 1024, "LDS budget of one CU");
+// on-chip variant: + the pose's bone rows by joint slot (24 x 12 floats) and a staging area for the next pass's rays
+// (64 floats of ray_batch rows, 64 floats of first / last depths)
+constexpr int LDSR_SK = LDSR_TOTAL;
+constexpr int LDSR_STAGE = LDSR_SK + J * 12 * 4;
+constexpr int LDSR_TOTAL_OC = LDSR_STAGE + 512;
+static_assert(LDSR_SK % 16 == 0 && LDSR_STAGE % 16 == 0 && LDSR_TOTAL_OC <= 160 * 1024, "LDS budget of one CU (on-chip variant)");
 
 __device__ __forceinline__ f32x4 load_bias16(const float* bias, int tile, int g) {
     const float4 b = *reinterpret_cast<const float4*>(bias + tile * 16 + 4 * g);
@@ -147,6 +157,81 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
         v0[6] = v0[7] = v1[6] = v1[7] = 0.0f;
         mma_row16<V, NT16, T>(acc, p, st, XV16 + pr, Op<V>::cvt(v0), Op<V>::cvt(v1));
         if (!hooked) { hook(); hooked = true; }
+    }
+}
+
+// 64 dwords by LDS-DMA with a per-lane source offset (bytes from a wave-uniform base) to LDS dst + 4 lane
+__device__ __forceinline__ void dma_dwords(const void* base, uint32_t lane_off, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
+}
+
+// One (ray, joint slot) record row of the on-chip variant -- what pg_rayrec.hip writes to HBM for the record variant:
+// a = R_j o + t_j, b = R_j d (encoders.py:8-37) and, in a.w, the squared distance of the ray's sampled segment
+// [z0, z1] from the joint (pass_far_mask).  sk = the joint's three bone rows (R | t), ray = (o, d).
+__device__ __forceinline__ void ab_row(const float* sk, const float* ray, float z0, float z1, float4* dst) {
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float ax = fmaf(sk[2], oz, fmaf(sk[1], oy, fmaf(sk[0], ox, sk[3])));
+    const float ay = fmaf(sk[6], oz, fmaf(sk[5], oy, fmaf(sk[4], ox, sk[7])));
+    const float az = fmaf(sk[10], oz, fmaf(sk[9], oy, fmaf(sk[8], ox, sk[11])));
+    const float bx = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
+    const float by = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
+    const float bz = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
+    const float bb = bx * bx + by * by + bz * bz, ab = ax * bx + ay * by + az * bz;
+    float zs = bb > 0.0f ? -ab / bb : z0;
+    zs = fminf(fmaxf(zs, fminf(z0, z1)), fmaxf(z0, z1));
+    const float qx = fmaf(zs, bx, ax), qy = fmaf(zs, by, ay), qz = fmaf(zs, bz, az);
+    const float d2 = qx * qx + qy * qy + qz * qz;
+    dst[0] = make_float4(ax, ay, az, d2 == d2 ? d2 : 0.0f);
+    dst[1] = make_float4(bx, by, bz, 0.0f);
+}
+
+// On-chip variant: the view layer's direction part Y[ray][joint][out] = sum_k W_vd[out, (joint, k)] T[ray][joint][k]
+// (pg_layout.h "factorised view layer") for the limbs in range of the pass, straight into the LDS image the second
+// stage reads (y_apply16) -- no per-ray record in HBM.  One stream chunk per limb: 32 A fragments [joint slot 6 g' +
+// jj][out tile t]; wave w takes joint group g' = w & 3 and out tiles 4 (w >> 2) .. + 3, with the pass's rays as the 16
+// MFMA columns: B = the 27 view values of (ray, joint), from the record's b = R_j d: e = b / |b|, rows (e, sin e,
+// cos e, .., sin 8 e, cos 8 e) per component (encoders.py:172-193, cutoff_embedder.py:45-46), hardware sin / cos.
+// Limbs out of range of the whole pass keep whatever an earlier pass left (zeros at first): every weight that
+// multiplies them is below 2^-24.
+template <typename V, typename ST>
+__device__ __forceinline__ void y_segment16(ST& st, int gmask, const uint8_t* ab, uint8_t* ylds, int nrm1, int wave, int lane) {
+    using E = typename Op<V>::E;
+    const int g = lane >> 4, col = lane & 15;
+    const int gj = wave & 3, t0 = 4 * (wave >> 2);
+    const uint8_t* row = ab + min(col, nrm1) * REC_AB_BYTES + (JG * gj) * 32 + 16;         // b rows of this wave's joint slots
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < JG; ++jj) {
+        if ((gmask >> jj) & 1) continue;
+        st.enter_split();
+#pragma unroll
+        for (int i = 0; i < ST::PER; ++i) st.piece(i);
+        const float4 b = *reinterpret_cast<const float4*>(row + jj * 32);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(b.x * b.x + b.y * b.y + b.z * b.z, 1e-24f)) * 0.15915494309189535f;
+        const float rx = b.x * inv, ry = b.y * inv, rz = b.z * inv;       // e in revolutions
+        float tv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 8 * g + i;                    // 0 .. 31 (27 used): component c = k / 9, row r9 = k % 9
+            const int c = (k >= 9) + (k >= 18), r9 = k - 9 * c;
+            const float ec = c == 0 ? rx : (c == 1 ? ry : rz);
+            const int f = (r9 - 1) >> 1;
+            const float ang = ec * (float)(1 << (f < 0 ? 0 : f)) + (((r9 - 1) & 1) ? 0.25f : 0.0f);
+            const float sv = __builtin_amdgcn_sinf(ang);
+            tv[i] = k >= 27 ? 0.0f : (r9 == 0 ? ec * 6.283185307179586f : sv);
+        }
+        const V bf = Op<V>::cvt(tv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + q;
+            const V av = __builtin_bit_cast(V, *reinterpret_cast<const uint4*>(st.at(0, (gj * NTV16 + t) * UNIT_BYTES)));
+            f32x4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            c4 = Op16<V>::mfma(av, bf, c4);
+            if (col <= nrm1) {
+                E* dst = reinterpret_cast<E*>(ylds + col * REC_Y_BYTES + t * 1024 + (gj * 16 + 4 * g) * 16 + 2 * jj);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 8] = (E)c4[r];
+            }
+        }
     }
 }
 
@@ -268,8 +353,13 @@ __device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds,
 
 // TAPS = the debug tap of pg_stage_eval (stage 0: pre-activation of density layer 0) compiled in: its own
 // instantiation, launched only when a dump is asked for
-template <typename V, bool FC, bool TAPS>
+// OC = the on-chip variant (one pose shared by the launch's rays, no frame codes -- BASELINE config 2): no per-ray
+// records in HBM and no record kernel in front.  The (a, b) rows of a pass's rays are formed by the workgroup a pass
+// ahead from the rays themselves (LDS-DMA of their ray_batch rows and first / last depths, the pose's bone rows kept in
+// LDS), and the view layer's direction part Y by y_segment16 from limb chunks of the weight stream.
+template <typename V, bool FC, bool TAPS, bool OC>
 __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
+    static_assert(!(OC && FC), "the on-chip variant has no frame-code pseudo joint");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDSR_BIAS);
     float* cut = reinterpret_cast<float*>(smem + LDSR_CUT);
@@ -277,15 +367,26 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     const int g = lane >> 4, col = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    StreamR st{a.wstream, smem + LDSR_RING, wave, lane, 0u, 0u, 0u, lds0 + LDSR_RING, lane16};
+    using ST = typename std::conditional<OC, StreamRO, StreamR>::type;
+    ST st{a.wstream, smem + LDSR_RING, wave, lane, 0u, 0u, 0u, lds0 + LDSR_RING, lane16};
     const uint8_t* rec_ab = reinterpret_cast<const uint8_t*>(a.rec_ab);
+    const float* sk_lds = reinterpret_cast<const float*>(smem + LDSR_SK);
+    const float* stage = reinterpret_cast<const float*>(smem + LDSR_STAGE);
 
     for (int i = tid; i < BIAS16_FLOATS; i += NTHR) bias[i] = a.bias[i];
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     // by joint SLOT (pg_layout.h slot16_joint): the folded sigmoid constants of both embedders, and the squared distance
     // beyond which a joint's cutoff weight 1 / (1 + 2^(v tl + cs)) is below 2^-24
     if (tid < 48) cut[tid] = -a.cutoff[(tid < J ? 0 : J) + slot_joint_dev(tid < J ? tid : tid - J)] * (tid < J ? tlv : tld);
-    else if (tid < 72) { const float far = a.cutoff[slot_joint_dev(tid - 48)] + 24.0f / tlv; cut[tid] = far * far; }
+    else if (tid < 72) {    // (of both embedders: the same mask drops a limb's view-direction part)
+        const int jt = slot_joint_dev(tid - 48);
+        const float far = fmaxf(a.cutoff[jt] + 24.0f / tlv, a.cutoff[J + jt] + 24.0f / tld);
+        cut[tid] = far * far;
+    }
+    if (OC) {       // the pose's bone rows by joint slot; an all-zero Y image (limbs no pass has computed yet)
+        for (int i = tid; i < J * 12; i += NTHR) reinterpret_cast<float*>(smem + LDSR_SK)[i] = a.skts[slot_joint_dev(i / 12) * 16 + i % 12];
+        for (int i = tid; i < MAXR_F * REC_Y_BYTES / 16; i += NTHR) reinterpret_cast<uint4*>(smem + LDSR_Y)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 #if defined(PG_YOUNG_PRIO)
     // experiment: the second-dispatched wave of each SIMD loses every issue arbitration to the older one and is what
     // the older one waits for at the chunk barriers: one static priority for that half (no per-segment flips)
@@ -300,8 +401,16 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     long long p0 = (long long)blockIdx.x * PTS;
     int r0 = __builtin_amdgcn_readfirstlane((int)(p0 / a.S));
     int off0 = __builtin_amdgcn_readfirstlane((int)(p0 - (long long)r0 * a.S));
-    // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched a pass ahead
-    if ((int)blockIdx.x < a.n_iters && wave < LDS_AB_BYTES / 1024)
+    // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched (OC: formed) a pass ahead
+    if (OC) {
+        lds_barrier();                      // the bone rows are in LDS
+        if (tid < MAXR_F * J) {
+            const int k = tid / J, sl = tid - k * J;
+            const long long ray = min((long long)r0 + k, (long long)a.n_rays - 1);
+            ab_row(sk_lds + sl * 12, a.rays + ray * 11, a.z[ray * a.S], a.z[ray * a.S + a.S - 1],
+                   reinterpret_cast<float4*>(smem + LDSR_AB + k * REC_AB_BYTES + sl * 32));
+        }
+    } else if ((int)blockIdx.x < a.n_iters && wave < LDS_AB_BYTES / 1024)
         dma_piece(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSR_AB + wave * 1024, lane16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -385,6 +494,17 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         // (a, b) buffer of the pass before may be overwritten.  Wave w fetches out tile w of this pass's MAXR_F Y
         // records and waves 0..3 a piece of the NEXT pass's (a, b); both are in LDS, and visible, one chunk entry on.
         auto fetch_records = [&]() {
+            if (OC) {
+                // the NEXT pass's rays: 64 floats of their ray_batch rows from the first one on (wave 0) and their first
+                // and last depths (wave 1), lane offsets clamped to the arrays; in LDS one chunk entry on
+                const long long rn = min((long long)r0n, (long long)a.n_rays - 1);
+                if (wave == 0) dma_dwords(a.rays, (uint32_t)(min(rn * 11 + lane_p, (long long)a.n_rays * 11 - 1) * 4), lds0 + LDSR_STAGE);
+                else if (wave == 1) {
+                    const long long ray = min(rn + min(lane_p >> 1, MAXR_F - 1), (long long)a.n_rays - 1);
+                    dma_dwords(a.z, (uint32_t)((ray * a.S + ((lane_p & 1) ? a.S - 1 : 0)) * 4), lds0 + LDSR_STAGE + 256);
+                }
+                return;
+            }
             const uint8_t* ysrc = a.rec_y + (size_t)r0 * REC_Y_BYTES + wave * 1024;
 #pragma unroll
             for (int k = 0; k < MAXR_F; ++k)         // slots past the pass's last ray re-fetch that ray (an L2 hit, not HBM; no branch)
@@ -418,9 +538,25 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) fa[u][c] = relu_pack16<V>(acc[2 * u][c], acc[2 * u + 1][c], true);
         }
+        if constexpr (OC) {
+            // the view layer's direction part of this pass's rays, for the limbs in range
+            y_segment16<V>(st, gmask, smem + LDSR_AB + abuf * LDS_AB_BYTES, smem + LDSR_Y, nrm1, wave, lane_p);
+        }
         PG_STAMP(2);
         // ---- layers 1..4 ----
         hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 1 * NT16);
+        if constexpr (OC) {
+            // The NEXT pass's (a, b) rows from the staged rays.  The fetch was issued in layer 0's first chunk, possibly
+            // between that chunk's refill pieces: the counted wait of the SECOND entry behind it covers it, and that
+            // entry's barrier makes the other wave's share visible -- layer 1's four entries lie in between.  15 of each
+            // wave's lanes take one (ray, joint slot) each.
+            const int item = wave * 15 + (lane_p & 15);         // (per pass: addresses derived from it are not hoisted out of the pass loop)
+            if (lane_p < 15) {
+                const int k = item / J, sl = item - k * J;
+                ab_row(sk_lds + sl * 12, stage + 11 * k, stage[64 + 2 * k], stage[64 + 2 * k + 1],
+                       reinterpret_cast<float4*>(smem + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES + k * REC_AB_BYTES + sl * 32));
+            }
+        }
         hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 2 * NT16);
         hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 3 * NT16);
         hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 4 * NT16);
@@ -538,28 +674,33 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC, bool TAPS>
+template <typename V, bool FC, bool TAPS, bool OC>
 static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16r_kernel<V, FC, TAPS>;
+    auto k = eval16r_kernel<V, FC, TAPS, OC>;
+    constexpr int lds = OC ? LDSR_TOTAL_OC : LDSR_TOTAL;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
-    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), LDSR_TOTAL, attr_done);
+    const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), lds, attr_done);
     if (ae != hipSuccess) return ae;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), LDSR_TOTAL, stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NTHR), lds, stream, a);
     return hipGetLastError();
 }
 
 template <typename V>
-static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int grid, hipStream_t s) {
-    if (a.dbg && a.dbg_stage != 99) return framecode ? launch_eval16r<V, true, true>(a, grid, s) : launch_eval16r<V, false, true>(a, grid, s);
-    return framecode ? launch_eval16r<V, true, false>(a, grid, s) : launch_eval16r<V, false, false>(a, grid, s);
+static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip, int grid, hipStream_t s) {
+    const bool taps = a.dbg && a.dbg_stage != 99;
+    if (onchip) return taps ? hipErrorInvalidValue : launch_eval16r<V, false, false, true>(a, grid, s);     // (no debug taps in this variant)
+    if (taps) return framecode ? launch_eval16r<V, true, true, false>(a, grid, s) : launch_eval16r<V, false, true, false>(a, grid, s);
+    return framecode ? launch_eval16r<V, true, false, false>(a, grid, s) : launch_eval16r<V, false, false, false>(a, grid, s);
 }
 
 }  // namespace pgd
 
-// needs S >= pgl::FACT_MIN_S, the R weight stream (pack_stream_r), the 16-row bias table (pack_bias_s) and the
-// per-ray records of pg_rayrec.hip in a.rec_ab / a.rec_y
-extern "C" int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int grid, void* stream) {
+// needs S >= pgl::FACT_MIN_S, the 16-row bias table (pack_bias_s) and
+//   onchip = 0: the R weight stream (pack_stream_r) and the per-ray records of pg_rayrec.hip in a.rec_ab / a.rec_y
+//   onchip = 1: the on-chip R stream (pack_stream_r(..., onchip)), one pose for all rays (a.pose_stride == 0), no frame codes
+extern "C" int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int onchip, int grid, void* stream) {
     using namespace pgd;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return (int)(fp16 ? dispatch_eval16r<f16x8>(*a, framecode, grid, s) : dispatch_eval16r<bf16x8>(*a, framecode, grid, s));
+    if (onchip && (framecode || a->pose_stride != 0)) return (int)hipErrorInvalidValue;
+    return (int)(fp16 ? dispatch_eval16r<f16x8>(*a, framecode, onchip, grid, s) : dispatch_eval16r<bf16x8>(*a, framecode, onchip, grid, s));
 }

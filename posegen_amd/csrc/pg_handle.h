@@ -16,6 +16,7 @@ struct NetState {
     int n_codes = 0;
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
     uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the per-ray record kernel (pg_rayrec.hip)
+    uint8_t* d_stream_ro[PG_PREC_COUNT] = {};     // 16x16x32 kernel, on-chip variant (no per-ray records): stream
     uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip): stream,
     float* d_bias_s = nullptr;                    // ... and its 16-row bias table
     uint8_t* d_stream_cr = nullptr;               // compensated-fp16 kernel, record variant (pg_evalc.hip REC): stream,

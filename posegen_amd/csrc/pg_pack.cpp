@@ -240,13 +240,14 @@ int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& o
 
 // ---- 16x16x32 kernel (pg_eval16r.hip): units are 16 out rows x 32 k; lane (g, row) holds k = 32u + 8g + 0..7.
 // Segments start on chunk boundaries, except the rgb head, which follows the alpha / view tiles directly. ----
-int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out) {
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out, bool onchip) {
     if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
     if (t.viewf_w.size() != (size_t)VW * W) return -4;
     const bool is_bf = precision == PG_PREC_BF16;
     struct Seg { int mat, no, nu; bool kmajor, xseq; int colbase; bool pad; };
     std::vector<Seg> prog;
     prog.push_back({MAT_L0, NT16, XU16, true, true, 0, true});
+    if (onchip) prog.push_back({MAT_VIEW, NTV16, G16 * JG, false, false, W, true});      // (marker: the limb chunks, packed below)
     for (int l = 1; l <= 4; ++l) prog.push_back({MAT_L0 + l, NT16, HU16, false, false, 0, true});
     prog.push_back({MAT_L0 + 5, NT16, HU16, false, false, CH_X, true});
     prog.push_back({MAT_L0 + 5, NT16, XU16, true, true, 0, true});
@@ -255,6 +256,24 @@ int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out)
     prog.push_back({MAT_RGB, 1, VW / 32, false, false, 0, true});
     out.clear();
     for (const Seg& sg : prog) {
+        if (sg.mat == MAT_VIEW) {       // chunk jj = limb jj: unit [g' (joint slot 6 g' + jj)][out tile t], lane (g, row): k = 8 g + e
+            for (int jj = 0; jj < JG; ++jj)
+                for (int gp = 0; gp < G16; ++gp)
+                    for (int tt = 0; tt < NTV16; ++tt) {
+                        const size_t base = out.size();
+                        out.resize(base + UNIT_BYTES, 0);
+                        const int j = slot16_joint(JG * gp + jj);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int ch = vd_channel(j, 8 * (lane >> 4) + e);
+                                if (ch < 0) continue;
+                                const float wv = t.w(MAT_VIEW, 16 * tt + (lane & 15), W + ch);
+                                const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
+                                std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                            }
+                    }
+            continue;
+        }
         for (int L = 0; L < sg.nu * sg.no; ++L) {
             const int u = sg.kmajor ? L / sg.no : L % sg.nu;
             const int o = sg.kmajor ? L % sg.no : L / sg.nu;
@@ -277,7 +296,7 @@ int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out)
         }
         if (sg.pad) out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
-    return out.size() == (size_t)R::NCHUNK * CHUNK_BYTES ? 0 : -2;
+    return out.size() == (size_t)(onchip ? R::NCHUNK_OC : R::NCHUNK) * CHUNK_BYTES ? 0 : -2;
 }
 
 void pack_bias_s(const NetTensors& t, std::vector<float>& out) {

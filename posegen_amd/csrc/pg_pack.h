@@ -36,7 +36,9 @@ int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, s
                 std::vector<int>* seg_chunk_base = nullptr, bool rec = false);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
 // stream and bias table of the 16x16x32 kernel (pg_program.h R, pg_layout.h "small tile")
-int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out);
+// `onchip`: the variant without per-ray records (pg_eval16r.hip OC): + one chunk per limb of the view layer's direction
+// weights behind layer 0 ([joint slot 6 g + jj][out tile16 t], k = the joint's 27 view values: vd_channel)
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out, bool onchip = false);
 void pack_bias_s(const NetTensors& t, std::vector<float>& out);
 // Y-stage weights of the record kernel (pg_rayrec.hip): [wave 8][unit n][64 lanes x 16 B]; unit n of
 // wave w = (joint slot16_joint(vy_slot(w, n/2)), k-unit n%2) of out tile w&3 as an MFMA B operand.

@@ -64,6 +64,12 @@ constexpr int CH_AVR = cdiv(U_AV + U_RGB, UPC);         // 3
 constexpr int NCHUNK = 2 * CH_L0X + 7 * CH_HID + CH_AVR;        // 47
 constexpr int C_L5X = CH_L0X + 5 * CH_HID;              // 28: first chunk of the skip layer's x part (its limb chunks, like layer 0's from 0)
 constexpr int NLIMB = JG;                               // limb chunks at the head of both x segments
+// on-chip variant (pg_eval16r.hip OC): + one chunk per limb of the view layer's direction weights, [joint slot 6 g + jj][out
+// tile16 t] fragments (k = the 27 view values of the joint), right behind layer 0
+constexpr int C_Y = CH_L0X;                             // 8
+constexpr int NCHUNK_OC = NCHUNK + NLIMB;               // 53
+constexpr int C_L5X_OC = C_L5X + NLIMB;                 // 34
+static_assert(G16 * NTV16 == UPC, "a limb's direction weights (4 joints x 8 out tiles) are exactly one chunk");
 // 16x16x32 MFMAs per 32-point group: two per unit, plus the second stage of the view layer for one ray
 constexpr int MFMA16_PER_GROUP = 2 * (2 * XU16 * NT16 + 7 * HU16 * NT16 + U_AV + U_RGB) + 2 * NTV16;
 // Y-stage weights of the record kernel (pg_rayrec.hip): per wave (out tile w&3, joint half w>>2) two B fragments

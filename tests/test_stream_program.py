@@ -64,7 +64,7 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
-    if (fact and prec != PREC_FP16C) or fact == 2:      # Y-stage weights (the compensated kernel: record variant only)
+    if (fact and fact != 3 and prec != PREC_FP16C) or fact == 2:      # Y-stage weights (the compensated kernel: record variant only)
         n = C.c_int64()
         rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(n))
         assert rc == 0, lib.pg_last_error(None)
@@ -331,6 +331,17 @@ def emulate_r(stream, bias16, chunk_bytes, prec, x, cfg, fact):
 
     xs = seq_vals(xseq16_channel, XU16 * 8, x[:, :432])
     tiles = segment(NT16, True, xs, XU16, [bias_tile(o) for o in range(NT16)])
+    y_onchip = None
+    if fact[2] is None:     # on-chip variant: six limb chunks of direction weights behind layer 0, unit [g' (slot 6 g' + jj)][out tile t]
+        t16 = q16(fact[0].astype(np.float32), prec)
+        y_onchip = np.zeros((J + 1, VW), dtype=np.float32)
+        for jj in range(JG):
+            for gp in range(4):
+                j = PERM16[JG * gp + jj]
+                for t in range(NTV16):
+                    a = unit(gp * NTV16 + t)                                # [row, g, e]: k = 8 g + e
+                    y_onchip[j, 16 * t:16 * t + 16] = np.einsum("rge,ge->r", a, t16[j].reshape(4, 8))
+        y_onchip = q16(y_onchip, prec)
     hv = hidden_vals(tiles)
     for l in range(1, 5):
         hv = hidden_vals(segment(NT16, False, hv, HU16, [bias_tile(l * NT16 + o) for o in range(NT16)]))
@@ -342,7 +353,7 @@ def emulate_r(stream, bias16, chunk_bytes, prec, x, cfg, fact):
     av = segment(NTV16 + 1, False, hv, HU16, [bias_tile(BS_ALPHA + o) for o in range(NTV16 + 1)])
     sigma, vt = av[0][0], av[1:]
     fc = bool(cfg.framecode_ch)
-    yq = y_stage(fact[2], fact[0], fc, prec)                # the ray's Y record [25, 128], 16-bit
+    yq = y_onchip if y_onchip is not None else y_stage(fact[2], fact[0], fc, prec)      # the ray's Y record [25, 128], 16-bit
     wq = q16(fact[1].astype(np.float32), prec)              # [pt, 24]
     for g in range(4):
         for e in range(8):
@@ -507,7 +518,7 @@ def test_packed_compensated_stream_reproduces_mlp(fc, rec):
 
 @pytest.mark.parametrize("prec,quant,tol", [(PREC_FP32, None, 2e-4), (PREC_BF16, "bf16", 2e-2), (PREC_FP16, "fp16", 4e-3)])
 @pytest.mark.parametrize("fc", [False, True])
-@pytest.mark.parametrize("fact", [False, True])
+@pytest.mark.parametrize("fact", [False, True, 3])
 def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
     try:
         _ffi.load_library()
@@ -515,6 +526,8 @@ def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
         pytest.skip(str(e))
     if fact and prec == PREC_FP32:
         pytest.skip("the fp32 kernel keeps the direct view layer")
+    if fact == 3 and fc:
+        pytest.skip("the on-chip variant of the 16x16x32 kernel has no frame codes")
     cfg = h36m_config() if fc else surreal_config()
     w = syn.make_weights(cfg, 3)
     stream, bias, chunk_bytes, vy = pack(w, cfg, prec, fact)
