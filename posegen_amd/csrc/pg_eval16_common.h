@@ -47,6 +47,9 @@ template <> struct Op<f16x8> {
     }
 };
 
+#ifndef PG_PROGRESS_PRIO
+#define PG_PROGRESS_PRIO 0    // 0: off; 4 / 2: priority steps per chunk (next_a)
+#endif
 #ifndef PG_SPREAD_DMA
 #define PG_SPREAD_DMA 1       // weight-ring refill spread over the chunk (Stream::enter_split)
 #endif
@@ -139,6 +142,21 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
         for (int k = 0; k < LA; ++k)
             if (k <= rem) st.issue(p.r[(L + k) % NS], q + k);
     }
+#if PG_PROGRESS_PRIO
+    // The two waves of a SIMD share its issue port, oldest first: the older one runs ahead through a chunk and then waits
+    // at the next chunk barrier while the younger one finishes alone (stamps: the older waves spend a fifth of a pass in
+    // s_barrier).  Issue priority by PROGRESS instead: a wave lowers its own priority as it advances through the chunk, so
+    // whichever wave is behind wins the arbitration and the two move through the chunk together, each filling the
+    // other's stalls.
+    if (q % (UPC / PG_PROGRESS_PRIO) == 0) {
+        switch (3 - (q / (UPC / PG_PROGRESS_PRIO)) * (4 / PG_PROGRESS_PRIO)) {       // (constant after unrolling; the builtin wants a literal)
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    }
+#endif
     if (LA <= rem) st.issue(p.r[(L + LA) % NS], q + LA);
     if (PG_SPREAD_DMA) {
         // refill piece i of the freed slot goes out at unit i*PSTRIDE+PG_DMA_PHASE of this
