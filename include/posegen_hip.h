@@ -369,6 +369,12 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
                        float* rgb, float* disp, float* acc, float* alpha, float* weights,
                        int n_importance, float* z_fine /*[n,S+N] or NULL*/);
 
+/* Test / measurement aid: on = 0 makes the fused 16-bit and compensated kernels compute every limb of the density input
+ * for every point instead of leaving out the limbs a wave / a pass is out of cutoff range of (a joint farther than
+ * cutoff_dist + 24 / (tau log2 e) has a cutoff weight 1 - sigmoid(tau (v - c)) below 2^-24, cutoff_embedder.py:139-146:
+ * DESIGN.md 2.1).  Default on.  The two settings agree to ~1e-7 per skipped product. */
+int pg_set_far_skip(pg_handle* h, int on);
+
 /* Optional in-library timing of the fused embed+MLP kernel (the dominant kernel): while
  * enabled, every launch is bracketed by hipEvents on the caller's stream.  pg_profile_read
  * synchronises, returns the number of launches, their summed device time [ms] and the

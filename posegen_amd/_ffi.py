@@ -74,6 +74,7 @@ PROTOTYPES = {
     "pg_set_framecodes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "pg_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_set_far_skip": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
                                  C.c_int, C.c_int, C.c_int, C.POINTER(PgOutputs)]),
     "pg_calibrate_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

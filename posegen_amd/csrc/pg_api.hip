@@ -340,6 +340,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     a.tau_v = h->tau[0];
     a.tau_d = h->tau[1];
     a.dbg_stage = dbg_stage;
+    a.far_skip = h->far_skip ? 1 : 0;
     const int pts = sa ? pg_eval16_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
     if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
         return pg_fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
@@ -644,6 +645,13 @@ int pg_set_chunk(pg_handle* h, int chunk) {
     if (chunk <= 0) return pg_fail(h, PG_EINVAL, "pg_set_chunk: chunk must be positive, got %d", chunk);
     h->cfg.chunk = chunk;
     PG_FORWARD(h, pg_set_chunk(hh, chunk));
+    return PG_OK;
+}
+
+int pg_set_far_skip(pg_handle* h, int on) {
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_set_far_skip: null handle");
+    h->far_skip = on != 0;
+    PG_FORWARD(h, pg_set_far_skip(hh, on));
     return PG_OK;
 }
 

@@ -38,6 +38,7 @@ struct EvalArgs {
     int n_iters;              // workgroup passes = ceil(n_points / points per pass)
     float tau_v, tau_d;
     int dbg_stage;            // which activation `dbg` receives (see pg_stage_eval)
+    int far_skip;             // 1: limbs out of cutoff range are skipped (pg_eval16r.hip, pg_evalc.hip REC); 0: every limb computed
 };
 
 // Kernel arguments of the per-ray record kernel (pg_rayrec.hip) in front of a factorised 16-bit launch.

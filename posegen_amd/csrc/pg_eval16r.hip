@@ -425,6 +425,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     int gmask = 0;
 #if !defined(PG_NO_FAR_SKIP)
     gmask = pass_far_mask(smem + LDSR_AB, rays_of_pass(p0, off0), cut + 2 * J + JG * g, g, col);
+    if (!a.far_skip) gmask = 0;
 #endif
     st.start((uint32_t)gmask);
 
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 const bool near = fminf(ax * ax + ay * ay + az * az, bx * bx + by * by + bz * bz) < far2[jj];
                 if (__builtin_amdgcn_ballot_w64(near) == 0ull) farmask |= 1 << jj;
             }
-            farmask = __builtin_amdgcn_readfirstlane(farmask);
+            farmask = __builtin_amdgcn_readfirstlane(a.far_skip ? farmask : 0);
         }
 #endif
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
 #if !defined(PG_NO_FAR_SKIP)
         gmask_n = pass_far_mask(smem + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES, rays_of_pass(p0 + step, off0n),
                                 opaque_ptr(cut + 2 * J + JG * g_p), g_p, lane_p & 15);
+        if (!a.far_skip) gmask_n = 0;
 #endif
         st.nx_mask = (uint32_t)gmask_n;
         // ---- sigma head + view layer (feature layer folded in, view directions from the Y records) + rgb head,

@@ -573,6 +573,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     if (REC) {
 #if !defined(PG_NO_FAR_SKIP)
         gmask = pass_far_mask_c(smem + LDSC_AB, rays_of_pass(p0, off0), cut + 2 * J + JH * h, h, pt);
+        if (!a.far_skip) gmask = 0;
 #endif
         st.start((uint32_t)gmask);
     }
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
                 const float qx = fmaf(zz, hi.x, lo.x), qy = fmaf(zz, hi.y, lo.y), qz = fmaf(zz, hi.z, lo.z);
                 if (__builtin_amdgcn_ballot_w64(qx * qx + qy * qy + qz * qz < far2[jj]) == 0ull) wmask |= 1 << jj;
             }
-            wmask = __builtin_amdgcn_readfirstlane(wmask);
+            wmask = __builtin_amdgcn_readfirstlane(a.far_skip ? wmask : 0);
 #endif
         }
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the (a, b)
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #if !defined(PG_NO_FAR_SKIP)
             gmask_n = pass_far_mask_c(smem + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES, rays_of_pass(p0 + step, off0n),
                                       opaque_ptr(cut + 2 * J + JH * h), h, pt);
+            if (!a.far_skip) gmask_n = 0;
 #endif
             st.nx_mask = (uint32_t)gmask_n;
         }

@@ -53,6 +53,7 @@ struct pg_handle {
     std::vector<pg_handle*> peers;
     hipStream_t own_stream = nullptr;
     float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
+    bool far_skip = true;            // pg_set_far_skip (test / measurement aid)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;

@@ -138,6 +138,10 @@ class HipRenderer:
             self._check(self.lib.pg_set_chunk(self.handle, int(chunk)))
             self._chunk = int(chunk)
 
+    def set_far_skip(self, on=True):
+        """Test / measurement aid (pg_set_far_skip): off = the fused kernels compute every limb for every point."""
+        self._check(self.lib.pg_set_far_skip(self.handle, 1 if on else 0))
+
     def profile_enable(self, on=True):
         self._check(self.lib.pg_profile_enable(self.handle, 1 if on else 0))
 
