@@ -237,6 +237,20 @@ int ensure_stream_cr(pg_handle* h, int which) {
     return PG_OK;
 }
 
+// the on-chip form of that variant (one pose per launch, no frame codes): its stream
+int ensure_stream_co(pg_handle* h, int which) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (ns.d_stream_co) return PG_OK;
+    std::vector<uint8_t> packed;
+    const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), PG_PREC_FP16C, false, true, packed, nullptr, true, true);
+    if (rc != 0) return pg_fail(h, PG_EINVAL, "compensated-fp16 on-chip stream packing failed (%d)", rc);
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_stream_co), packed.size()));
+    PG_HIP(h, hipMemcpy(ns.d_stream_co, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -260,7 +274,8 @@ int ensure_mode_streams(pg_handle* h, int which, int mode) {
             return rc ? rc : ensure_stream(h, which, prec, false);
         }
         if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) {     // + the direct form's stream (32 <= S < 64)
-            const int rc = ensure_stream_cr(h, which);
+            int rc = ensure_stream_cr(h, which);
+            if (!rc && h->cfg.framecode_ch == 0) rc = ensure_stream_co(h, which);
             if (rc) return rc;
         }
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
@@ -303,9 +318,10 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fc = h->cfg.framecode_ch > 0;
     const bool onchip = sa && fact && !dbg && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
-    const bool crec = compk && use_comp_rec(S);                   // per-ray records + the record variant of pg_evalc.hip
+    const bool conchip = compk && use_comp_rec(S) && (!dbg || dbg_stage == 98) && use_onchip(fc, pose_stride);   // the record variant of pg_evalc.hip without per-ray records
+    const bool crec = compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec)
-           : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
+           : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const int y_bytes = crec ? RECC_Y_BYTES : REC_Y_BYTES;
     if ((recs || crec) && (rc = ensure_rec(h, n, y_bytes))) return rc;
@@ -314,7 +330,8 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : crec ? ns.d_stream_cr : ns.d_stream[prec][fact];
+    a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : conchip ? ns.d_stream_co : crec ? ns.d_stream_cr
+              : ns.d_stream[prec][fact];
     a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : nullptr;
     a.bias = (recs || onchip) ? ns.d_bias_s : ns.d_bias;
     if (recs || crec) {
@@ -380,7 +397,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     }
     int e = (recs || onchip) ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, onchip, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
-          : compk ? pg_launch_evalc(&a, fc, crec, grid, stream)
+          : compk ? pg_launch_evalc(&a, fc, conchip ? 2 : crec ? 1 : 0, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
         PG_HIP(h, hipEventRecord(e1, static_cast<hipStream_t>(stream)));
@@ -537,6 +554,7 @@ void pg_destroy(pg_handle* h) {
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
         if (ns.d_stream_cr) (void)hipFree(ns.d_stream_cr);
+        if (ns.d_stream_co) (void)hipFree(ns.d_stream_co);
         if (ns.d_vyc) (void)hipFree(ns.d_vyc);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
@@ -583,6 +601,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
     if (ns.d_stream_cr) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_cr)); ns.d_stream_cr = nullptr; }
+    if (ns.d_stream_co) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_co)); ns.d_stream_co = nullptr; }
     if (ns.d_vyc) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vyc)); ns.d_vyc = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
@@ -720,9 +739,10 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     cfg.framecode_ch = framecode_ch;
     std::vector<uint8_t> packed;
     const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
-    const bool crec = view_fact == 2 && precision == PG_PREC_FP16C;     // record variant of pg_evalc.hip
+    const bool crec = view_fact >= 2 && precision == PG_PREC_FP16C;     // record variant of pg_evalc.hip (3: its on-chip form)
     const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed, view_fact == 3)
-                         : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed, nullptr, crec);
+                         : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed, nullptr, crec,
+                                               crec && view_fact == 3);
     if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
     if (stream_bytes) *stream_bytes = (int64_t)packed.size();
     if (chunk_bytes) *chunk_bytes = CHUNK_BYTES;
@@ -825,7 +845,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
         return PG_OK;
     }
     if (compk && use_comp_rec(FACT_MIN_S)) {     // record variant of the compensated kernel (the usual case)
-        if (stream_bytes) *stream_bytes = (int64_t)pgp::C::NCHUNK_R * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0) ? pgp::C::NCHUNK_OC : pgp::C::NCHUNK_R) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::C::MFMA_PER_GROUP_R;
         return PG_OK;
     }

@@ -365,4 +365,30 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
 #define PG_STAMP(k) do {} while (0)
 #endif
 
+// ---- on-chip variants of the record kernels: the per-ray rows are formed by the workgroup itself ----
+// 64 dwords by LDS-DMA with a per-lane source offset (bytes from a wave-uniform base) to LDS dst + 4 lane
+__device__ __forceinline__ void dma_dwords(const void* base, uint32_t lane_off, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
+}
+
+// One (ray, joint slot) record row of the on-chip variants (pg_eval16r.hip OC, pg_evalc.hip OC) -- what pg_rayrec.hip writes to HBM for the record variant:
+// a = R_j o + t_j, b = R_j d (encoders.py:8-37) and, in a.w, the squared distance of the ray's sampled segment
+// [z0, z1] from the joint (pass_far_mask).  sk = the joint's three bone rows (R | t), ray = (o, d).
+__device__ __forceinline__ void ab_row(const float* sk, const float* ray, float z0, float z1, float4* dst) {
+    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+    const float ax = fmaf(sk[2], oz, fmaf(sk[1], oy, fmaf(sk[0], ox, sk[3])));
+    const float ay = fmaf(sk[6], oz, fmaf(sk[5], oy, fmaf(sk[4], ox, sk[7])));
+    const float az = fmaf(sk[10], oz, fmaf(sk[9], oy, fmaf(sk[8], ox, sk[11])));
+    const float bx = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
+    const float by = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
+    const float bz = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
+    const float bb = bx * bx + by * by + bz * bz, ab = ax * bx + ay * by + az * bz;
+    float zs = bb > 0.0f ? -ab / bb : z0;
+    zs = fminf(fmaxf(zs, fminf(z0, z1)), fmaxf(z0, z1));
+    const float qx = fmaf(zs, bx, ax), qy = fmaf(zs, by, ay), qz = fmaf(zs, bz, az);
+    const float d2 = qx * qx + qy * qy + qz * qz;
+    dst[0] = make_float4(ax, ay, az, d2 == d2 ? d2 : 0.0f);
+    dst[1] = make_float4(bx, by, bz, 0.0f);
+}
+
 }  // namespace pgd

@@ -160,39 +160,14 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
     }
 }
 
-// 64 dwords by LDS-DMA with a per-lane source offset (bytes from a wave-uniform base) to LDS dst + 4 lane
-__device__ __forceinline__ void dma_dwords(const void* base, uint32_t lane_off, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
-}
-
-// One (ray, joint slot) record row of the on-chip variant -- what pg_rayrec.hip writes to HBM for the record variant:
-// a = R_j o + t_j, b = R_j d (encoders.py:8-37) and, in a.w, the squared distance of the ray's sampled segment
-// [z0, z1] from the joint (pass_far_mask).  sk = the joint's three bone rows (R | t), ray = (o, d).
-__device__ __forceinline__ void ab_row(const float* sk, const float* ray, float z0, float z1, float4* dst) {
-    const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
-    const float ax = fmaf(sk[2], oz, fmaf(sk[1], oy, fmaf(sk[0], ox, sk[3])));
-    const float ay = fmaf(sk[6], oz, fmaf(sk[5], oy, fmaf(sk[4], ox, sk[7])));
-    const float az = fmaf(sk[10], oz, fmaf(sk[9], oy, fmaf(sk[8], ox, sk[11])));
-    const float bx = fmaf(sk[2], dz, fmaf(sk[1], dy, sk[0] * dx));
-    const float by = fmaf(sk[6], dz, fmaf(sk[5], dy, sk[4] * dx));
-    const float bz = fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx));
-    const float bb = bx * bx + by * by + bz * bz, ab = ax * bx + ay * by + az * bz;
-    float zs = bb > 0.0f ? -ab / bb : z0;
-    zs = fminf(fmaxf(zs, fminf(z0, z1)), fmaxf(z0, z1));
-    const float qx = fmaf(zs, bx, ax), qy = fmaf(zs, by, ay), qz = fmaf(zs, bz, az);
-    const float d2 = qx * qx + qy * qy + qz * qz;
-    dst[0] = make_float4(ax, ay, az, d2 == d2 ? d2 : 0.0f);
-    dst[1] = make_float4(bx, by, bz, 0.0f);
-}
-
 // On-chip variant: the view layer's direction part Y[ray][joint][out] = sum_k W_vd[out, (joint, k)] T[ray][joint][k]
 // (pg_layout.h "factorised view layer") for the limbs in range of the pass, straight into the LDS image the second
 // stage reads (y_apply16) -- no per-ray record in HBM.  One stream chunk per limb: 32 A fragments [joint slot 6 g' +
 // jj][out tile t]; wave w takes joint group g' = w & 3 and out tiles 4 (w >> 2) .. + 3, with the pass's rays as the 16
 // MFMA columns: B = the 27 view values of (ray, joint), from the record's b = R_j d: e = b / |b|, rows (e, sin e,
 // cos e, .., sin 8 e, cos 8 e) per component (encoders.py:172-193, cutoff_embedder.py:45-46), hardware sin / cos.
-// Limbs out of range of the whole pass keep whatever an earlier pass left (zeros at first): every weight that
-// multiplies them is below 2^-24.
+// Limbs out of range of the whole pass keep whatever an earlier pass left (zeros at first): the second stage multiplies
+// them by exactly zero.
 template <typename V, typename ST>
 __device__ __forceinline__ void y_segment16(ST& st, int gmask, const uint8_t* ab, uint8_t* ylds, int nrm1, int wave, int lane) {
     using E = typename Op<V>::E;
@@ -631,6 +606,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 wd[0][jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
                 q1(jj, qx, qy, qz);
                 wd[1][jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+                // a limb left out of the pass has weights below 2^-24 in every point: exactly zero instead, so that what the
+                // on-chip variant's Y image still holds for the limb from an earlier pass can never reach a result
+                if (OC && ((gmask >> jj) & 1)) wd[0][jj] = wd[1][jj] = 0.0f;
             }
             y_apply16<V, FC>(vacc, smem + LDSR_Y, wd, myr, lane_p);
 #pragma unroll

@@ -46,6 +46,8 @@ using VC = f16x8;
 using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
 // record variant: no view-direction segment; the joint-pair chunks of both x segments can be left out of a pass (Stream MASK_NX)
 using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR>;
+// on-chip variant (no per-ray records in HBM): the joint-pair chunks of the view layer's direction weights sit behind layer 0
+using StreamCRO = Stream<NWAVE_C, pgp::C::NCHUNK_OC, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR_OC, pgp::C::C_YC>;
 #ifndef PG_NSC
 #define PG_NSC 4
 #endif
@@ -61,6 +63,15 @@ constexpr int LDSC_Y = LDSC_AB + 2 * LDS_ABC_BYTES;
 constexpr int LDS_TOTAL_CR = LDSC_Y + MAXR_CR * RECC_Y_BYTES;
 static_assert(LDSC_BIAS % 16 == 0 && LDSC_CUT % 16 == 0 && LDSC_AB % 16 == 0 && LDSC_Y % 16 == 0, "LDS alignment");
 static_assert(LDS_TOTAL_CR <= 160 * 1024, "LDS budget of one CU");
+// on-chip variant (OC): the (a, b) buffers hold exactly MAXR_CR rays (no DMA-piece granularity), behind the Y image the
+// pose's bone rows by joint slot (24 x 12 floats) and a staging area for the next pass's rays (64 floats of ray_batch
+// rows, 64 floats of first / last depths)
+constexpr int LDSO_ABSZ = MAXR_CR * REC_AB_BYTES;
+constexpr int LDSO_Y = LDSC_AB + 2 * LDSO_ABSZ;
+constexpr int LDSO_SK = LDSO_Y + MAXR_CR * RECC_Y_BYTES;
+constexpr int LDSO_STAGE = LDSO_SK + J * 12 * 4;
+constexpr int LDS_TOTAL_CO = LDSO_STAGE + 512;
+static_assert(LDSO_Y % 16 == 0 && LDSO_SK % 16 == 0 && LDSO_STAGE % 16 == 0 && LDS_TOTAL_CO <= 160 * 1024, "LDS budget of one CU (on-chip variant)");
 
 // ---- the fp16 pair of a value: x1 = f16(x) (RNE), x2 = f16(x1 + S (x - x1)) ---------------------
 // Both halves come from ONE conversion result: left to hipcc under -ffp-contract=on, the fragment
@@ -435,6 +446,79 @@ __device__ __forceinline__ void x_segment_cr(f32x16* acc, ST& st, const float* a
     }
 }
 
+// On-chip variant: the view layer's direction part Y[ray][joint][out] = sum_k W_vd[out, (joint, k)] T[ray][joint][k]
+// (pg_layout.h "factorised view layer") of the pass's rays for the joint pairs in range of the pass, as the split A
+// operands the second stage reads (RECC layout) -- no per-ray record in HBM.  One stream chunk per joint pair p: unit
+// pairs [k-unit u of 8 view values][out tile o]; wave w takes out tile w.  The MFMA runs transposed: A = the rays' view
+// values (row r = ray r of slot p from lane half 0, row 4 + r = ray r of slot 12 + p from lane half 1, every other lane
+// zero, so that the two halves' joints do not mix), B = the weights (column = out channel); lane (h, col) then holds
+// Y[ray r][slot 12 h + p][32 w + col] in accumulator register r.  T from the record's b = R_j d: e = b / |b|, rows
+// (e, sin e, cos e, .., sin 8 e, cos 8 e) per component (encoders.py:172-193, cutoff_embedder.py:45-46), hardware
+// sin / cos, split like an activation; Y / S split like a weight (pg_rayrec.hip recc_unit).  Pairs out of range of the
+// whole pass keep whatever an earlier pass left (zeros at first): the second stage multiplies them by exactly zero.
+template <typename ST>
+__device__ __forceinline__ void y_segment_c(ST& st, int gmask, const uint8_t* ab, uint8_t* ylds, int nrm1, int wave, int lane, float s129) {
+    const int h = lane >> 5, ray = (lane & 31) - 4 * h;
+    const bool live = ray >= 0 && ray <= nrm1;
+    const uint8_t* brow = ab + (live ? ray : 0) * REC_AB_BYTES + JH * h * 32 + 16;        // b rows of this lane half's joint slots
+    uint8_t* ydst = ylds + wave * 4096 + lane * 16;
+    PairPipe<NSC> pp;
+#pragma unroll 1
+    for (int pj = 0; pj < JH; ++pj) {
+        if ((gmask >> pj) & 1) continue;
+        st.enter_split();
+        uint4 w0[4], w1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint8_t* src = st.at(0, (u * NTV + wave) * 2048);
+            w0[u] = *reinterpret_cast<const uint4*>(src);
+            w1[u] = *reinterpret_cast<const uint4*>(src + 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < ST::PER; ++i) piece_c(pp, st, i);
+        const float4 b = *reinterpret_cast<const float4*>(brow + pj * 32);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(b.x * b.x + b.y * b.y + b.z * b.z, 1e-24f));
+        const float ev[3] = {b.x * inv, b.y * inv, b.z * inv};
+        const float rv[3] = {ev[0] * 0.15915494309189535f, ev[1] * 0.15915494309189535f, ev[2] * 0.15915494309189535f};
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float tv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * u + e, c = k / ROWS_D, r9 = k % ROWS_D;        // (constants after unrolling)
+                if (k >= 3 * ROWS_D) tv[e] = 0.0f;
+                else if (r9 == 0) tv[e] = ev[c];
+                else {
+                    const float ang = rv[c] * (float)(1 << ((r9 - 1) >> 1));
+                    tv[e] = ((r9 - 1) & 1) ? __builtin_amdgcn_cosf(ang) : __builtin_amdgcn_sinf(ang);
+                }
+            }
+            // gfx940-family trans forwarding: a VALU instruction may not read the result of v_sin / v_cos in the very next
+            // issue slot; hipcc pads its own instructions, not the inline asm of conv_a that consumes these values
+            asm volatile("s_nop 0" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+            FragC f = frag_of(tv, s129);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { f.x1[q] = live ? f.x1[q] : 0u; f.x2[q] = live ? f.x2[q] : 0u; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_v(f.x1), __builtin_bit_cast(VC, w0[u]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag_v(f.x2), __builtin_bit_cast(VC, w1[u]), acc, 0, 0, 0);
+        }
+        uint8_t* d0 = ydst + (pj >> 3) * 2048 + (pj & 7) * 2;
+#pragma unroll
+        for (int r = 0; r < MAXR_CR; ++r) {
+            if (r > nrm1) break;                                // (wave-uniform)
+            float v = acc[r] * (1.0f / (float)COMP_S);
+            asm volatile("" : "+v"(v));                         // one rounded value for both halves (no fused convert of the product)
+            const _Float16 y1 = (_Float16)v;
+            const float y1f = (float)y1;
+            *reinterpret_cast<_Float16*>(d0 + r * RECC_Y_BYTES) = (_Float16)((float)(COMP_S - 1) * y1f);
+            *reinterpret_cast<_Float16*>(d0 + r * RECC_Y_BYTES + 1024) = (_Float16)fmaf((float)COMP_S, v - y1f, y1f);
+        }
+    }
+}
+
 // joint pairs out of cutoff range of EVERY point of a pass, from the per-ray records (AB[ray][slot].w = squared distance
 // of the ray's sampled segment from the joint, pg_rayrec.hip): one ballot per joint slot over the two lane halves'
 // joints x the rays of the pass (lane = ray; lanes past the last ray repeat it).  The same in every wave.
@@ -511,8 +595,15 @@ __device__ __forceinline__ void ray_table_c(const EvalArgs& a, float* rt, int r0
 // per-ray records of pg_rayrec.hip (ray_records_c_kernel) and are fetched by LDS-DMA -- no table build, no barriers
 // at the pass boundary, no 64-bit divisions, and the 648-wide view input (336 MFMAs, 11 chunks of weights and its
 // per-point products and splits) becomes <= 32 MFMAs on the point's 24 cutoff weights.
-template <bool FC, bool TAPS, bool REC>
+// OC = the on-chip form of the record variant (one pose shared by the launch's rays, no frame codes -- BASELINE config 2):
+// no per-ray records in HBM and no record kernel in front.  The (a, b) rows of a pass's rays are formed by the workgroup
+// a pass ahead from the rays themselves (LDS-DMA of their ray_batch rows and first / last depths, the pose's bone rows
+// kept in LDS), and the view layer's direction part Y by y_segment_c from joint-pair chunks of the weight stream.
+template <bool FC, bool TAPS, bool REC, bool OC = false>
 __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
+    static_assert(!OC || (REC && !FC && !TAPS), "the on-chip variant is a form of the record variant without frame codes");
+    constexpr int ABSZ = OC ? LDSO_ABSZ : LDS_ABC_BYTES;          // one (a, b) buffer
+    constexpr int YOFF = OC ? LDSO_Y : LDSC_Y;                    // the Y image of the pass's rays
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + (REC ? LDSC_BIAS : LDS_BIAS));
     float* cut = reinterpret_cast<float*>(smem + (REC ? LDSC_CUT : LDS_CUT));
@@ -521,8 +612,10 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     const int h = lane >> 5, pt = lane & 31;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    using ST = typename std::conditional<REC, StreamCR, StreamC>::type;
+    using ST = typename std::conditional<OC, StreamCRO, typename std::conditional<REC, StreamCR, StreamC>::type>::type;
     ST st{a.wstream, smem + LDS_RING, wave, lane, 0u, 0u, 0u, lds0 + LDS_RING, lane16};
+    const float* sk_lds = reinterpret_cast<const float*>(smem + LDSO_SK);
+    const float* stage = reinterpret_cast<const float*>(smem + LDSO_STAGE);
     // bias tile indices of this variant's table
     constexpr int TB_ALPHA = REC ? BTC_ALPHA : BT_ALPHA, TB_VIEWF = REC ? BTC_VIEWF : BT_VIEWF, TB_RGB = REC ? BTC_RGB : BT_RGB;
 
@@ -539,8 +632,16 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     const float tlv = a.tau_v * 1.4426950408889634f, tld = a.tau_d * 1.4426950408889634f;
     if (REC) {      // by joint SLOT (pg_layout.h slotc_joint), + the squared distance beyond which a cutoff weight is below 2^-24
         if (tid < 48) cut[tid] = -a.cutoff[(tid < J ? 0 : J) + slotc_joint_dev(tid < J ? tid : tid - J)] * (tid < J ? tlv : tld);
-        else if (tid < 72) { const float far = a.cutoff[slotc_joint_dev(tid - 48)] + 24.0f / tlv; cut[tid] = far * far; }
+        else if (tid < 72) {        // (of both embedders: the on-chip variant's mask drops a pair's view-direction part too)
+            const int jt = slotc_joint_dev(tid - 48);
+            const float far = fmaxf(a.cutoff[jt] + 24.0f / tlv, a.cutoff[J + jt] + 24.0f / tld);
+            cut[tid] = far * far;
+        }
     } else if (tid < 48) cut[tid] = -a.cutoff[tid] * (tid < J ? tlv : tld);
+    if (OC) {       // the pose's bone rows by joint slot; an all-zero Y image (pairs no pass has computed yet)
+        for (int i = tid; i < J * 12; i += NTHR_C) reinterpret_cast<float*>(smem + LDSO_SK)[i] = a.skts[slotc_joint_dev(i / 12) * 16 + i % 12];
+        for (int i = tid; i < MAXR_CR * RECC_Y_BYTES / 16; i += NTHR_C) reinterpret_cast<uint4*>(smem + LDSO_Y)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     float s129 = (float)COMP_S;
     asm volatile("" : "+s"(s129));              // one SGPR for the whole kernel, not a literal per use
     if (!REC) st.start();
@@ -556,8 +657,16 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         dq = __builtin_amdgcn_readfirstlane((int)(step / a.S)); dr = __builtin_amdgcn_readfirstlane((int)(step % a.S));
         r0 = __builtin_amdgcn_readfirstlane((int)(p0 / a.S));
         off0 = __builtin_amdgcn_readfirstlane((int)(p0 - (long long)r0 * a.S));
-        // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched a pass ahead
-        if ((int)blockIdx.x < a.n_iters && wave < LDS_ABC_BYTES / 1024)
+        // (a, b) of the first pass's rays into buffer 0; every later pass finds its own fetched (OC: formed) a pass ahead
+        if (OC) {
+            lds_barrier();                      // the bone rows are in LDS
+            if (tid < MAXR_CR * J) {
+                const int k = tid / J, sl = tid - k * J;
+                const long long ray = min((long long)r0 + k, (long long)a.n_rays - 1);
+                ab_row(sk_lds + sl * 12, a.rays + ray * 11, a.z[ray * a.S], a.z[ray * a.S + a.S - 1],
+                       reinterpret_cast<float4*>(smem + LDSC_AB + k * REC_AB_BYTES + sl * 32));
+            }
+        } else if ((int)blockIdx.x < a.n_iters && wave < LDS_ABC_BYTES / 1024)
             dma_piece_c(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSC_AB + wave * 1024, lane16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
@@ -604,7 +713,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
             const int tl_ = off0 + last, ti = off0 + wave * 32 + pt;
             nrm1 = (tl_ >= S1) + (tl_ >= S2);
             myr = min((ti >= S1) + (ti >= S2), nrm1);
-            ab = opaque_ptr(reinterpret_cast<const float*>(smem + LDSC_AB + abuf * LDS_ABC_BYTES + myr * REC_AB_BYTES) + JH * h * 8);
+            ab = opaque_ptr(reinterpret_cast<const float*>(smem + LDSC_AB + abuf * ABSZ + myr * REC_AB_BYTES) + JH * h * 8);
             off0n = off0 + dr; r0n = r0 + dq;
             if (off0n >= a.S) { off0n -= a.S; ++r0n; }
         } else {
@@ -642,6 +751,17 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         // pieces, all of it has landed -- and is visible to every wave -- one chunk entry on (in-order vmcnt).
         auto fetch_records = [&]() {
             if (!REC) return;
+            if (OC) {
+                // the NEXT pass's rays: 64 floats of their ray_batch rows from the first one on (wave 0) and their first
+                // and last depths (wave 1), lane offsets clamped to the arrays; in LDS one chunk entry on
+                const long long rn = min((long long)r0n, (long long)a.n_rays - 1);
+                if (wave == 0) dma_dwords(a.rays, (uint32_t)(min(rn * 11 + lane, (long long)a.n_rays * 11 - 1) * 4), lds0 + LDSO_STAGE);
+                else if (wave == 1) {
+                    const long long ray = min(rn + min(lane >> 1, MAXR_CR - 1), (long long)a.n_rays - 1);
+                    dma_dwords(a.z, (uint32_t)((ray * a.S + ((lane & 1) ? a.S - 1 : 0)) * 4), lds0 + LDSO_STAGE + 256);
+                }
+                return;
+            }
             constexpr int PW = MAXR_CR * (RECC_Y_BYTES / 1024) / NWAVE_C;      // 12 pieces per wave
             constexpr int PR = RECC_Y_BYTES / 1024;                             // 16 pieces per record
             const uint8_t* ysrc = a.rec_y + (size_t)r0 * RECC_Y_BYTES;
@@ -654,6 +774,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
                 dma_piece_c(rec_ab + (long long)min(r0n, a.n_rays - 1) * REC_AB_BYTES + wave * 1024,
                             lds0 + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES + wave * 1024, lane16);
         };
+        static_assert(MAXR_CR * 11 <= 64 && 2 * MAXR_CR <= 64, "the staged rays fit one dword DMA each");
 
         PG_STAMP(1);
         f32x16 accA[NT], accB[NT];
@@ -668,6 +789,8 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a.dbg[gp * W + 32 * o + rho(r, h)] = accA[o][r];
         }
+        if constexpr (OC)   // the view layer's direction part of this pass's rays, for the joint pairs in range
+            y_segment_c(st, gmask, smem + LDSC_AB + abuf * ABSZ, smem + LDSO_Y, nrm1, wave, lane, s129);
         PG_STAMP(2);
         // ---- layers 1..4 (ping-pong between the two accumulator sets) ----
         auto srcA = [&](int u, int e) { return accA[u >> 1][8 * (u & 1) + e]; };
@@ -675,6 +798,27 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 1 * NT + o, h);
         segment_c<NT, HU, true>(accB, st, srcA, s129);
+        if constexpr (OC) {
+            // The NEXT pass's (a, b) rows from the staged rays.  The fetch was issued in layer 0's first chunk, possibly
+            // between that chunk's refill pieces: the counted wait of the SECOND entry behind it covers it, and that
+            // entry's barrier makes the other wave's share visible -- layer 1's eight entries lie in between.  18 of
+            // each wave's lanes take one (ray, joint slot) each.
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));        // (addresses derived from it are formed here, not ahead of the pass loop)
+            if (lane_p < MAXR_CR * J / NWAVE_C) {
+                const int item = wave * (MAXR_CR * J / NWAVE_C) + lane_p;
+                const int k = item / J, sl = item - k * J;
+                ab_row(sk_lds + sl * 12, stage + 11 * k, stage[64 + 2 * k], stage[64 + 2 * k + 1],
+                       reinterpret_cast<float4*>(smem + LDSC_AB + (abuf ^ 1) * ABSZ + k * REC_AB_BYTES + sl * 32));
+            }
+#if defined(PG_DEBUG_Y)     // diagnosis build: the Y image and the (a, b) rows of workgroup 0's first pass
+            if (a.dbg && a.dbg_stage == 98 && blockIdx.x == 0 && it == 0) {
+                for (int i = tid; i < MAXR_CR * RECC_Y_BYTES / 4; i += NTHR_C) a.dbg[i] = reinterpret_cast<const float*>(smem + LDSO_Y)[i];
+                for (int i = tid; i < LDSO_ABSZ / 4; i += NTHR_C) a.dbg[MAXR_CR * RECC_Y_BYTES / 4 + i] = reinterpret_cast<const float*>(smem + LDSC_AB + abuf * ABSZ)[i];
+                if (tid == 0) { a.dbg[13000] = (float)nrm1; a.dbg[13001] = (float)gmask; }
+            }
+#endif
+        }
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 2 * NT + o, h);
         segment_c<NT, HU, true>(accA, st, srcB, s129);
@@ -709,7 +853,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         if (REC) {      // the NEXT pass's mask, from its (a, b) records (in LDS since this pass's second chunk entry): the ring's
                         // prefetch pointer wraps to the head of the stream within the next segments and must know it by then
 #if !defined(PG_NO_FAR_SKIP)
-            gmask_n = pass_far_mask_c(smem + LDSC_AB + (abuf ^ 1) * LDS_ABC_BYTES, rays_of_pass(p0 + step, off0n),
+            gmask_n = pass_far_mask_c(smem + LDSC_AB + (abuf ^ 1) * ABSZ, rays_of_pass(p0 + step, off0n),
                                       opaque_ptr(cut + 2 * J + JH * h), h, pt);
             if (!a.far_skip) gmask_n = 0;
 #endif
@@ -733,6 +877,9 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
                 const float4 hi = *reinterpret_cast<const float4*>(ab + jj * 8 + 4);
                 const float qx = fmaf(zz, hi.x, lo.x), qy = fmaf(zz, hi.y, lo.y), qz = fmaf(zz, hi.z, lo.z);
                 wd[jj] = cutoff_weight_fast(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz), tld, cutd[jj]);
+                // a pair left out of the pass has weights below 2^-24 in every point: exactly zero instead, so that what the
+                // on-chip form's Y image still holds for the pair from an earlier pass can never reach a result
+                if (OC && ((gmask >> jj) & 1)) wd[jj] = 0.0f;
             }
             if (TAPS && a.dbg && a.dbg_stage == 10 && valid) {
 #pragma unroll
@@ -757,7 +904,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
                         g0.x1[q] = myr == ray ? f0.x1[q] : 0u; g0.x2[q] = myr == ray ? f0.x2[q] : 0u;
                         g1.x1[q] = myr == ray ? f1.x1[q] : 0u; g1.x2[q] = myr == ray ? f1.x2[q] : 0u;
                     }
-                    const uint8_t* yb = smem + LDSC_Y + ray * RECC_Y_BYTES + lane * 16;
+                    const uint8_t* yb = smem + YOFF + ray * RECC_Y_BYTES + lane * 16;
 #pragma unroll
                     for (int o = 0; o < NTV; ++o) {
                         const uint4 a00 = *reinterpret_cast<const uint4*>(yb + (o * 4 + 0) * 1024);
@@ -823,10 +970,10 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <bool FC, bool TAPS, bool REC>
+template <bool FC, bool TAPS, bool REC, bool OC = false>
 static hipError_t launch_evalc(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = evalc_kernel<FC, TAPS, REC>;
-    constexpr int lds = REC ? LDS_TOTAL_CR : LDS_TOTAL_C;
+    auto k = evalc_kernel<FC, TAPS, REC, OC>;
+    constexpr int lds = OC ? LDS_TOTAL_CO : REC ? LDS_TOTAL_CR : LDS_TOTAL_C;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
     const hipError_t e = ensure_lds_attr(reinterpret_cast<const void*>(k), lds, attr_done);
     if (e != hipSuccess) return e;
@@ -844,9 +991,14 @@ static hipError_t dispatch_evalc(const EvalArgs& a, int framecode, int grid, hip
 
 // needs S >= pgl::COMP_MIN_S, rays (no explicit points) and the shape-C stream (pg_pack.cpp); rec: S >= pgl::FACT_MIN_S,
 // the record variant of the stream (pack_stream(..., rec = true)) and the records of ray_records_c_kernel in
-// a.rec_ab / a.rec_y
+// a.rec_ab / a.rec_y; rec == 2: its on-chip form (no records; the on-chip stream, a.pose_stride == 0, no frame codes, no
+// debug taps)
 extern "C" int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int rec, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rec == 2) {
+        if (framecode || a->pose_stride != 0 || (a->dbg && a->dbg_stage != 99 && a->dbg_stage != 98)) return (int)hipErrorInvalidValue;
+        return (int)pgd::launch_evalc<false, false, true, true>(*a, grid, s);
+    }
     return (int)(rec ? pgd::dispatch_evalc<true>(*a, framecode, grid, s) : pgd::dispatch_evalc<false>(*a, framecode, grid, s));
 }
 

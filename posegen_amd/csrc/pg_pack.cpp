@@ -96,12 +96,13 @@ void NetTensors::fold() {
     }
 }
 
-static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false, bool rec = false) {
+static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b = false, bool rec = false, bool onchip = false) {
     std::vector<Segment> s;
     auto hid = [](int cb) { return InUnits{SEQ_H, HSEQ, cb}; };
     if (shape == SHAPE_C) {         // compensated fp16 kernel (pg_evalc.hip): k-major everywhere, direct view layer
         const InUnits xin = rec ? InUnits{SEQ_XC, XUC * 8, 0} : InUnits{SEQ_X, XSEQ, 0};     // record variant: limb-wise x sequence
         s.push_back({MAT_L0, NT, true, {xin}});
+        if (onchip) s.push_back({MAT_VIEW, NTV, true, {}});       // (marker: the joint-pair chunks of direction weights, packed in pack_stream)
         for (int l = 1; l <= 4; ++l) s.push_back({MAT_L0 + l, NT, true, {hid(0)}});
         s.push_back({MAT_L0 + 5, NT, true, {hid(CH_X)}});
         s.push_back({MAT_L0 + 5, NT, true, {xin}});
@@ -138,7 +139,7 @@ static std::vector<Segment> program(int shape, bool fc, bool fact, bool fold_b =
 }
 
 int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vector<uint8_t>& out,
-                std::vector<int>* seg_chunk_base, bool rec) {
+                std::vector<int>* seg_chunk_base, bool rec, bool onchip) {
     const int shape = (precision == PG_PREC_BF16 || precision == PG_PREC_FP16) ? SHAPE_A
                     : (precision == PG_PREC_FP16C && fact) ? SHAPE_C : SHAPE_B;
     const bool is_f32 = precision == PG_PREC_FP32;
@@ -146,14 +147,40 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
     const bool comp = precision == PG_PREC_FP16C;
     const bool split = precision == PG_PREC_BF16X3 || precision == PG_PREC_FP16X3 || comp;     // two planes per unit
     if (precision < 0 || precision >= PG_PREC_COUNT) return -1;
+    if (onchip && (!rec || fc)) return -3;                  // the on-chip variant is a form of the record program, without frame codes
     if ((fact || rec) && shape != SHAPE_C) return -3;       // only PG_PREC_FP16C has a second program here (16-bit rays with >= 64 samples: pack_stream_r)
     if ((shape == SHAPE_A || split) && t.viewf_w.size() != (size_t)VW * W) return -4;   // NetTensors::fold() not called
     const int ue = is_f32 ? 4 : 8;
     const size_t unit_bytes = split ? 2048 : 1024;
     out.clear();
     if (seg_chunk_base) seg_chunk_base->clear();
-    for (const Segment& sg : program(shape, fc, fact, split, rec)) {
+    // the compensated pair of a weight W = 129 w: plane 0 = 128 w1 (exact), plane 1 = f16(w1 + 129 (w - w1)), w1 = f16(w)
+    auto comp_pair = [](float wv, uint16_t& p0, uint16_t& p1) {
+        const double wd = (double)wv / COMP_S;
+        const double w1 = f16_to_f32(f32_to_f16((float)wd));
+        p0 = f32_to_f16((float)((COMP_S - 1) * w1));
+        p1 = f32_to_f16((float)(w1 + COMP_S * (wd - w1)));
+    };
+    for (const Segment& sg : program(shape, fc, fact, split, rec, onchip)) {
         if (seg_chunk_base) seg_chunk_base->push_back((int)(out.size() / CHUNK_BYTES));
+        if (sg.inputs.empty()) {        // on-chip variant of shape C: chunk p = joint pair p (slots p and 12 + p), pairs [u][o]
+            for (int pj = 0; pj < JH; ++pj)
+                for (int u = 0; u < 4; ++u)
+                    for (int o = 0; o < NTV; ++o) {
+                        const size_t base = out.size();
+                        out.resize(base + 2048, 0);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int ch = vd_channel(slotc_joint(JH * (lane >> 5) + pj), 8 * u + e);
+                                if (ch < 0) continue;
+                                uint16_t p0, p1;
+                                comp_pair(t.w(MAT_VIEW, 32 * o + (lane & 31), W + ch), p0, p1);
+                                std::memcpy(&out[base + lane * 16 + e * 2], &p0, 2);
+                                std::memcpy(&out[base + 1024 + lane * 16 + e * 2], &p1, 2);
+                            }
+                    }
+            continue;
+        }
         // flatten the input units of this segment
         struct U { int seq, u, colbase; };
         std::vector<U> us;
@@ -175,12 +202,8 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
                         std::memcpy(&out[base + lane * 16 + e * 4], &wv, 4);
                     } else {
                         if (comp) {
-                            // W = 129 w: plane 0 = 128 w1 (exact), plane 1 = f16(w1 + 129 (w - w1)), w1 = f16(w)
-                            const double wd = (double)wv / COMP_S;
-                            const uint16_t w1b = f32_to_f16((float)wd);
-                            const double w1 = f16_to_f32(w1b);
-                            const uint16_t p0 = f32_to_f16((float)((COMP_S - 1) * w1));
-                            const uint16_t p1 = f32_to_f16((float)(w1 + COMP_S * (wd - w1)));
+                            uint16_t p0, p1;
+                            comp_pair(wv, p0, p1);
                             std::memcpy(&out[base + lane * 16 + e * 2], &p0, 2);
                             std::memcpy(&out[base + 1024 + lane * 16 + e * 2], &p1, 2);
                             continue;
@@ -199,7 +222,7 @@ int pack_stream(const NetTensors& t, int precision, bool fc, bool fact, std::vec
         out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
     const size_t nchunk = shape == SHAPE_A ? (size_t)A::NCHUNK
-                        : shape == SHAPE_C ? (size_t)(rec ? C::NCHUNK_R : C::NCHUNK) : (split ? B::NCHUNK_FOLD : B::NCHUNK);
+                        : shape == SHAPE_C ? (size_t)(onchip ? C::NCHUNK_OC : rec ? C::NCHUNK_R : C::NCHUNK) : (split ? B::NCHUNK_FOLD : B::NCHUNK);
     if (out.size() != nchunk * CHUNK_BYTES) return -2;   // packer and kernel programs disagree
     return 0;
 }

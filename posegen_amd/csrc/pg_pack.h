@@ -32,8 +32,10 @@ struct NetTensors {
 // precisions' second program (rays with >= 64 samples, pg_eval16r.hip) is pack_stream_r.
 // `rec` (with fact, PG_PREC_FP16C only): the record variant of that kernel -- no view-direction segment, the view
 // directions arrive as per-ray Y records (pack_vyc, pg_rayrec.hip).
+// `onchip` (with rec, no frame codes): the variant without per-ray records (pg_evalc.hip OC): + one chunk per joint pair of the
+// view layer's direction weights behind layer 0 (pg_program.h C::C_YC).
 int pack_stream(const NetTensors& t, int precision, bool framecode, bool fact, std::vector<uint8_t>& out,
-                std::vector<int>* seg_chunk_base = nullptr, bool rec = false);
+                std::vector<int>* seg_chunk_base = nullptr, bool rec = false, bool onchip = false);
 void pack_bias(const NetTensors& t, std::vector<float>& out);
 // stream and bias table of the 16x16x32 kernel (pg_program.h R, pg_layout.h "small tile")
 // `onchip`: the variant without per-ray records (pg_eval16r.hip OC): + one chunk per limb of the view layer's direction

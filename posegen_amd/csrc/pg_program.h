@@ -129,6 +129,13 @@ constexpr int C_L5XR = CH_L0XR + 5 * CH_HID;            // 55: first chunk of th
 constexpr int NPAIRJ = JH;                              // joint-pair chunks at the head of both x segments
 static_assert(2 * NT == PPC, "a joint pair's two unit rows are exactly one chunk");
 constexpr int MFMA_PER_GROUP_R = 2 * (2 * XUC * NT + 7 * HU * NT + HU * (NTV + 1) + HU / 2) + 2 * 2 * NTV;
+// on-chip variant (pg_evalc.hip OC: one pose per launch, no frame codes): no per-ray records; + one chunk per joint pair of the
+// view layer's direction weights right behind layer 0: unit pairs [k-unit u of 8 view values (4)][out tile o (NTV)], lane
+// (h, col) = out channel 32 o + col, values 8 u + e of joint slot 12 h + p (vd_channel order, 27 used)
+constexpr int C_YC = CH_L0XR;                           // 15
+constexpr int NCHUNK_OC = NCHUNK_R + NPAIRJ;            // 104
+constexpr int C_L5XR_OC = C_L5XR + NPAIRJ;              // 67
+static_assert(4 * NTV == PPC, "a joint pair's direction weights (4 k-units x 4 out tiles) are exactly one chunk");
 }  // namespace C
 
 }  // namespace pgp

@@ -252,8 +252,10 @@ def test_per_ray_poses_equal_the_per_pose_calls(prec):
         r.close()
     # The 16-bit modes render a one-pose call with the on-chip variant of the 16x16x32 kernel and a per-ray-pose call
     # with its record variant: the same products, formed and summed in a different order, so equal to a few operand
-    # roundings instead of bitwise (the exact modes run one kernel either way: bitwise).
-    tol = {"bf16": 4e-3, "fp16": 5e-4}.get(prec, 0.0)
+    # roundings instead of bitwise; the compensated kernel likewise (the record kernel forms the view layer's direction
+    # part in fp32 MFMAs from an accurate sincos, the on-chip form in compensated fp16 from the hardware sin / cos: both
+    # ~1e-6 of the exact value).  fp32 runs one kernel either way: bitwise.
+    tol = {"bf16": 4e-3, "fp16": 5e-4, "fp16c": 2e-5}.get(prec, 0.0)
     for k in ("rgb_map", "acc_map", "disp_map"):
         w = which if both[k].dim() == 1 else which[:, None]
         want = torch.where(w, one_b[k], one_a[k])

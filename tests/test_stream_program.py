@@ -417,6 +417,23 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
     xfn, xn = (xseqc_channel, XUC * 8) if rec is not None else (xseq_channel, XSEQ)
     xs = pair_vals(xfn, xn, x[:, :432])
     tiles = segment(NT, [(xs, xn)], tiles_of(0, NT))
+    y_onchip = None
+    if rec is not None and rec[2] is None:
+        # on-chip form (pg_evalc.hip y_segment_c): twelve joint-pair chunks of direction weights behind layer 0, unit pairs
+        # [k-unit u of 8 view values][out tile o], lane (h, col) = out channel 32 o + col, values 8 u + e of joint slot
+        # 12 h + p; the ray's view values split like an activation
+        t32 = rec[0].astype(np.float32)
+        t1 = h16(t32)
+        t2 = h16(t1 + np.float32(S) * (t32 - t1))
+        y_onchip = np.zeros((J + 1, VW), dtype=np.float32)
+        for pj in range(JH):
+            for u in range(4):
+                for o in range(NTV):
+                    P = (pj * 4 + u) * NTV + o
+                    a0, a1 = wv.unit(2 * P), wv.unit(2 * P + 1)     # [col, h, e]
+                    for h in range(2):
+                        j = PERMC[JH * h + pj]
+                        y_onchip[j, 32 * o:32 * o + 32] += a0[:, h, :] @ t1[j, 8 * u:8 * u + 8] + a1[:, h, :] @ t2[j, 8 * u:8 * u + 8]
     for l in range(1, 5):
         tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(l * NT, NT))
     tiles = segment(NT, [(hidden(tiles), HSEQ)], tiles_of(5 * NT, NT))
@@ -436,9 +453,12 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
         # like an activation; slots per vyc_slot_joint
         tray, wpt, vyc = rec
         fc = bool(cfg.framecode_ch)
-        wy = vyc.view(np.float32).reshape(J + 1, 28, VW)
         y = np.zeros((J + 1, VW), dtype=np.float32)
-        for sl in range(J + (1 if fc else 0)):                    # weight blocks are in SLOT order (pack_vyc), y by joint
+        if y_onchip is not None:
+            y = y_onchip
+        else:
+            wy = vyc.view(np.float32).reshape(J + 1, 28, VW)
+        for sl in range(J + (1 if fc else 0) if y_onchip is None else 0):       # weight blocks are in SLOT order (pack_vyc), y by joint
             j = PERMC[sl] if sl < J else J
             acc = np.zeros(VW, dtype=np.float32)
             for k in range(28):
@@ -470,7 +490,7 @@ def emulate_c(stream, bias, chunk_bytes, x, cfg, rec=None):
 
 
 @pytest.mark.parametrize("fc", [False, True])
-@pytest.mark.parametrize("rec", [False, True])
+@pytest.mark.parametrize("rec", [False, True, 3])
 def test_packed_compensated_stream_reproduces_mlp(fc, rec):
     """The fp16c stream as the kernel consumes it (pairs of planes, k-major, every segment on a chunk
     boundary) against the fp32 oracle: the compensation itself is what is tested -- plain fp16 is at
@@ -479,9 +499,11 @@ def test_packed_compensated_stream_reproduces_mlp(fc, rec):
         _ffi.load_library()
     except _ffi.HipLibraryError as e:
         pytest.skip(str(e))
+    if rec == 3 and fc:
+        pytest.skip("the on-chip form has no frame-code pseudo joint")
     cfg = h36m_config() if fc else surreal_config()
     w = syn.make_weights(cfg, 3)
-    stream, bias, chunk_bytes, vyc = pack(w, cfg, PREC_FP16C, 2 if rec else True)
+    stream, bias, chunk_bytes, vyc = pack(w, cfg, PREC_FP16C, 3 if rec == 3 else 2 if rec else True)
     rng = np.random.RandomState(0)
     x = rng.uniform(-1, 1, size=(32, 1080)).astype(np.float32)
     x[:, :360] *= rng.uniform(0, 1, size=(32, 1)).astype(np.float32)
