@@ -10,6 +10,10 @@
 // core/utils/ray_utils.py:285); poses, rays and the embedder's cutoff parameters get no gradient (the reference's
 // cutoff_dist has requires_grad=False; pose optimisation is out of scope).
 //
+// Two modes (the handle's precision): exact fp32 (below), and the 16-bit mode (PG_PREC_BF16): every activation and
+// activation gradient of the tape is STORED in bf16 (the embedding rows, the layer outputs, dH: half the bytes of a step
+// that is bound by them) and the large GEMMs multiply bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
+// weights, biases, raw, d_raw and every weight gradient stay fp32.
 // Exact fp32 arithmetic.  Training batches are small (N_rand = 2048 rays -> 131 k + 164 k points,
 // configs/surreal/surreal.txt:34), so the 1080-wide embedding and the layer activations are MATERIALISED in HBM
 // (14 KB per point, 4 GB per batch -- 1.4 % of the card) and every layer is a plain fp32 GEMM on
@@ -42,16 +46,32 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int XW = CH_X + CH_D + FC_CH;       // 1096: row of the materialised input (density | view | frame code or zeros)
 
+// element types of the tape: fp32, or bf16 bits in an unsigned short
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float ld_el(const void* p, long long i, bool bf) {
+    return bf ? bf2f(static_cast<const bf16_t*>(p)[i]) : static_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_el(void* p, long long i, float v, bool bf) {
+    if (bf) static_cast<bf16_t*>(p)[i] = f2bf(v); else static_cast<float*>(p)[i] = v;
+}
+template <typename T> __device__ __forceinline__ void put(T* x, int i, float v);
+template <> __device__ __forceinline__ void put<float>(float* x, int i, float v) { x[i] = v; }
+template <> __device__ __forceinline__ void put<bf16_t>(bf16_t* x, int i, float v) { x[i] = f2bf(v); }
+enum { DT_A = 1, DT_B = 2, DT_C = 4, DT_M = 8 };        // which operands of a GEMM are bf16: A, B, the result, the ReLU mask
+
 // ---- the 1080 (+16) network inputs of every point, one thread per (point, joint) --------------------------------
 // RelDist / VecNorm encoders on bone-local coordinates + cutoff positional embedding, channel order of the reference:
 // v part row * 24 + j, direction part 360 + 3 j + c, view part 432 + row * 72 + 3 j + c (core/encoders.py:8-37,
 // 101-122, 172-193; core/cutoff_embedder.py:111-174).  sin / cos of every octave directly (no doubling chain).
+template <typename XT>
 __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ rays, const float* __restrict__ z,
                                                          const float* __restrict__ pnoise, const float* __restrict__ skts,
                                                          long long pose_stride, const float* __restrict__ cams,
                                                          const float* __restrict__ codes, int n_codes, int fc,
                                                          const float* __restrict__ cutoff, float tau_v, float tau_d,
-                                                         long long n_points, int S, float* __restrict__ X) {
+                                                         long long n_points, int S, XT* __restrict__ X) {
     const long long idx = blockIdx.x * 256ll + threadIdx.x;
     if (idx >= n_points * J) return;
     const long long pt = idx / J;
@@ -66,20 +86,20 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
     const float qy = fmaf(sk[6], pz, fmaf(sk[5], py, fmaf(sk[4], px, sk[7])));
     const float qz = fmaf(sk[10], pz, fmaf(sk[9], py, fmaf(sk[8], px, sk[11])));
     const float v = sqrtf(qx * qx + qy * qy + qz * qz);
-    float* x = X + pt * XW;
+    XT* x = X + pt * XW;
     {
         const float w = 1.0f - 1.0f / (1.0f + expf(-tau_v * (v - cutoff[j])));
-        x[j] = v * w;
+        put(x, j, v * w);
         float f = 1.0f;
 #pragma unroll
         for (int k = 0; k < LV; ++k, f *= 2.0f) {
             float s, c;
             sincosf(f * v, &s, &c);
-            x[(1 + 2 * k) * J + j] = s * w;
-            x[(2 + 2 * k) * J + j] = c * w;
+            put(x, (1 + 2 * k) * J + j, s * w);
+            put(x, (2 + 2 * k) * J + j, c * w);
         }
         const float den = fmaxf(v, 1e-12f);
-        x[CH_V + 3 * j] = qx / den; x[CH_V + 3 * j + 1] = qy / den; x[CH_V + 3 * j + 2] = qz / den;
+        put(x, CH_V + 3 * j, qx / den); put(x, CH_V + 3 * j + 1, qy / den); put(x, CH_V + 3 * j + 2, qz / den);
     }
     {
         const float dx = rb[3], dy = rb[4], dz = rb[5];
@@ -87,31 +107,31 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
                       fmaf(sk[10], dz, fmaf(sk[9], dy, sk[8] * dx))};
         const float den = fmaxf(sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]), 1e-12f);
         const float w = 1.0f - 1.0f / (1.0f + expf(-tau_d * (v - cutoff[J + j])));
-        float* xd = x + CH_X;
+        XT* xd = x + CH_X;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float ev = e[c] / den;
-            xd[3 * j + c] = ev * w;
+            put(xd, 3 * j + c, ev * w);
             float f = 1.0f;
 #pragma unroll
             for (int k = 0; k < LD; ++k, f *= 2.0f) {
                 float s, co;
                 sincosf(f * ev, &s, &co);
-                xd[(1 + 2 * k) * (3 * J) + 3 * j + c] = s * w;
-                xd[(2 + 2 * k) * (3 * J) + 3 * j + c] = co * w;
+                put(xd, (1 + 2 * k) * (3 * J) + 3 * j + c, s * w);
+                put(xd, (2 + 2 * k) * (3 * J) + 3 * j + c, co * w);
             }
         }
     }
     if (j == 0) {
-        float* xc = x + CH_X + CH_D;
+        XT* xc = x + CH_X + CH_D;
         if (fc) {
             const float cam = cams ? cams[ray] : -1.0f;
             const int ci = cam < 0.0f ? n_codes : min((int)cam, n_codes - 1);      // row n_codes = the mean code
 #pragma unroll
-            for (int k = 0; k < FC_CH; ++k) xc[k] = codes[ci * FC_CH + k];
+            for (int k = 0; k < FC_CH; ++k) put(xc, k, codes[ci * FC_CH + k]);
         } else {
 #pragma unroll
-            for (int k = 0; k < FC_CH; ++k) xc[k] = 0.0f;
+            for (int k = 0; k < FC_CH; ++k) put(xc, k, 0.0f);
         }
     }
 }
@@ -122,11 +142,14 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict
 constexpr int GB = 64, GK = 16;
 enum { GEMM_ACC = 1, GEMM_RELU = 2 };
 
+// dt (DT_*): which of A, B, C are bf16 in HBM (this kernel multiplies in fp32 whatever they are stored as); GEMM_ACC adds
+// cin[m ldcin + n] (fp32; the result array itself in the fp32 mode)
 template <bool A_KCONT, bool B_KCONT>
-__global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
-                                                    const float* __restrict__ B, long long sbk, long long sbn,
-                                                    float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
-                                                    float* __restrict__ part) {
+__global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const void* __restrict__ A, long long sam, long long sak,
+                                                    const void* __restrict__ B, long long sbk, long long sbn,
+                                                    void* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                    float* __restrict__ part, int dt, const float* cin, long long ldcin) {
+    const bool abf = dt & DT_A, bbf = dt & DT_B;
     // gridDim.z > 1: K is split; slice z writes its tile to part[z][M][N] and reduce_parts_kernel adds the slices in
     // order (bitwise repeatable, unlike float atomics)
     __shared__ float As[GK][GB + 4], Bs[GK][GB + 4];
@@ -147,26 +170,26 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = kb + kq + i;
-                As[kq + i][m] = (m0 + m < M && k < k1) ? A[(long long)(m0 + m) * sam + (long long)k * sak] : 0.0f;
+                As[kq + i][m] = (m0 + m < M && k < k1) ? ld_el(A, (long long)(m0 + m) * sam + (long long)k * sak, abf) : 0.0f;
             }
         } else {
             const int m = (t & 15) * 4, k = kb + (t >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                As[t >> 4][m + i] = (m0 + m + i < M && k < k1) ? A[(long long)(m0 + m + i) * sam + (long long)k * sak] : 0.0f;
+                As[t >> 4][m + i] = (m0 + m + i < M && k < k1) ? ld_el(A, (long long)(m0 + m + i) * sam + (long long)k * sak, abf) : 0.0f;
         }
         if (B_KCONT) {
             const int n = t >> 2, kq = (t & 3) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = kb + kq + i;
-                Bs[kq + i][n] = (n0 + n < N && k < k1) ? B[(long long)k * sbk + (long long)(n0 + n) * sbn] : 0.0f;
+                Bs[kq + i][n] = (n0 + n < N && k < k1) ? ld_el(B, (long long)k * sbk + (long long)(n0 + n) * sbn, bbf) : 0.0f;
             }
         } else {
             const int n = (t & 15) * 4, k = kb + (t >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                Bs[t >> 4][n + i] = (n0 + n + i < N && k < k1) ? B[(long long)k * sbk + (long long)(n0 + n + i) * sbn] : 0.0f;
+                Bs[t >> 4][n + i] = (n0 + n + i < N && k < k1) ? ld_el(B, (long long)k * sbk + (long long)(n0 + n + i) * sbn, bbf) : 0.0f;
         }
         __syncthreads();
 #pragma unroll
@@ -180,13 +203,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mq + rho(r, kh);
             if (m >= M) continue;
-            float* c = C + (long long)m * ldc + n;
             float v = acc[r];
             if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
-            if (flags & GEMM_ACC) v += *c;
+            if (flags & GEMM_ACC) v += cin[(long long)m * ldcin + n];
             if (bias) v += bias[n];
             if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
-            *c = v;
+            st_el(C, (long long)m * ldc + n, v, dt & DT_C);
         }
     }
 }
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
                                                        const float* __restrict__ B, long long sbk, long long sbn,
                                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
                                                        const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
-                                                       float* __restrict__ part, float* __restrict__ rs_part) {
+                                                       float* __restrict__ part, float* __restrict__ rs_part, const float* cin, long long ldcin) {
     // mask: C(m,n) is zeroed where mask[m ldm + n] <= 0 (the ReLU backward of the layer that consumes C, fused);
     // rowsum (A m-contiguous only): sum_k A(m,k) (the bias gradient beside a weight gradient): block (x, z) writes the
     // share of its k-steps to rs_part[z * gridDim.x + x][M]; reduce_parts_kernel adds the shares in order.
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
                 float* c = C + (long long)m * ldc + n;
                 float v = acc[i][j][r];
                 if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
-                if (flags & GEMM_ACC) v += *c;
+                if (flags & GEMM_ACC) v += cin[(long long)m * ldcin + n];
                 v += bv;
                 if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
                 if (mask && !(mask[(long long)m * ldm + n] > 0.0f)) v = 0.0f;
@@ -301,63 +323,66 @@ __global__ __launch_bounds__(256) void sgemm128_kernel(int M, int N, int K, cons
     if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
 }
 
-// ---- the same GEMM with bf16 operands (fp32 in HBM, rounded on the way into LDS; fp32 accumulate): the 16-bit training
-// mode.  128 x 128 x 32 tiles on v_mfma_f32_32x32x16_bf16, LDS rows [row][32 k + 8 pad] bf16 (80-byte pitch: the 16-byte
-// fragment reads of a 16-lane group fall on 16 different bank quads), k-contiguous operands stored 4 k at a time,
-// k-strided ones as (k, k + 1) pairs.
-constexpr int BK = 32, BPITCH = BK + 8;
+// ---- the large GEMMs of the 16-bit training mode: bf16 operands in HBM (the tape's activations, the step's bf16 copies of
+// the weight matrices), fp32 accumulate.  128 x 128 x 64 tiles on v_mfma_f32_32x32x16_bf16, LDS rows [row][64 k + 8 pad] bf16
+// (144-byte pitch: the 16-byte fragment reads of a 16-lane group fall on 16 different bank quads), k-contiguous operands
+// stored 8 k at a time, k-strided ones transposed as (k, k + 1) pairs.  One k-step (16 KiB per operand) is in flight in
+// registers while the current one is multiplied: with ~3 workgroups per CU that is what keeps HBM busy -- at 32 k per step
+// the same kernel moved 1.7 TB/s.
+constexpr int BK = 64, BPITCH = BK + 8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8t;
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    const b2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, v);
-}
-
 template <bool KCONT>
-__device__ __forceinline__ void btile_fetch(float4 (&v)[4], const float* __restrict__ P, long long s_row, long long s_k,
-                                            int row0, int rows, int kb, int k1, int t) {
+__device__ __forceinline__ void btile_fetch_h(uint4 (&v)[4], const bf16_t* __restrict__ P, long long s_row, long long s_k,
+                                              int row0, int rows, int kb, int k1, int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KCONT) {            // 4 consecutive k of one row
-            const int idx = t + 256 * i, r = idx >> 3, k = kb + (idx & 7) * 4;
-            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)(row0 + r) * s_row + k);
-        } else {                // 4 consecutive rows of k = 2 kp and (i odd) 2 kp + 1
-            const int kp = (t >> 5) + 8 * (i >> 1), k = kb + 2 * kp + (i & 1), r = (t & 31) * 4;
-            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const float4*>(P + (long long)k * s_k + row0 + r);
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (KCONT) {            // 8 consecutive k of one row
+            const int idx = t + 256 * i, r = idx >> 3, k = kb + (idx & 7) * 8;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const uint4*>(P + (long long)(row0 + r) * s_row + k);
+        } else {                // 8 consecutive rows of k = 2 kp (i even) and 2 kp + 1 (i odd); neighbouring lanes take neighbouring
+                                // k pairs, so that the transposing stores below spread over the LDS banks (2-way, not 16-way)
+            const int kp = (t & 15) + 16 * (i >> 1), k = kb + 2 * kp + (i & 1), r = (t >> 4) * 8;
+            if (row0 + r < rows && k < k1) v[i] = *reinterpret_cast<const uint4*>(P + (long long)k * s_k + row0 + r);
         }
     }
 }
-
 template <bool KCONT>
-__device__ __forceinline__ void btile_store(unsigned short (*T)[BPITCH], const float4 (&v)[4], int t) {
+__device__ __forceinline__ void btile_store_h(unsigned short (*T)[BPITCH], const uint4 (&v)[4], int t) {
     if (KCONT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = t + 256 * i, r = idx >> 3, kq = (idx & 7) * 4;
-            *reinterpret_cast<uint2*>(&T[r][kq]) = make_uint2(pack_bf16(v[i].x, v[i].y), pack_bf16(v[i].z, v[i].w));
+            const int idx = t + 256 * i;
+            *reinterpret_cast<uint4*>(&T[idx >> 3][(idx & 7) * 8]) = v[i];
         }
-    } else {
+    } else {                    // row r + j gets the pair (k, k + 1) = (v[2 q].j, v[2 q + 1].j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kp = (t >> 5) + 8 * i, r = (t & 31) * 4;
-            const float4 a = v[2 * i], b = v[2 * i + 1];
-            *reinterpret_cast<unsigned*>(&T[r][2 * kp]) = pack_bf16(a.x, b.x);
-            *reinterpret_cast<unsigned*>(&T[r + 1][2 * kp]) = pack_bf16(a.y, b.y);
-            *reinterpret_cast<unsigned*>(&T[r + 2][2 * kp]) = pack_bf16(a.z, b.z);
-            *reinterpret_cast<unsigned*>(&T[r + 3][2 * kp]) = pack_bf16(a.w, b.w);
+        for (int q = 0; q < 2; ++q) {
+            const int kp = (t & 15) + 16 * q, r = (t >> 4) * 8;
+            const unsigned a[4] = {v[2 * q].x, v[2 * q].y, v[2 * q].z, v[2 * q].w}, b[4] = {v[2 * q + 1].x, v[2 * q + 1].y, v[2 * q + 1].z, v[2 * q + 1].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                *reinterpret_cast<unsigned*>(&T[r + 2 * c][2 * kp]) = (a[c] & 0xffffu) | (b[c] << 16);
+                *reinterpret_cast<unsigned*>(&T[r + 2 * c + 1][2 * kp]) = (a[c] >> 16) | (b[c] & 0xffff0000u);
+            }
         }
     }
 }
 
+// dt & DT_C / DT_M: the result / the ReLU mask is bf16; GEMM_ACC adds cin[m ldcin + n] (fp32)
+#ifndef PG_BGEMM_WGS
+#define PG_BGEMM_WGS 3        // workgroups per CU the register budget is held to (168 VGPRs: three waves per SIMD)
+#endif
 template <bool A_KCONT, bool B_KCONT>
-__global__ __launch_bounds__(256) void bgemm128_kernel(int M, int N, int K, const float* __restrict__ A, long long sam, long long sak,
-                                                       const float* __restrict__ B, long long sbk, long long sbn,
-                                                       float* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
-                                                       const float* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
-                                                       float* __restrict__ part, float* __restrict__ rs_part) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[TB][BPITCH], Bs[TB][BPITCH];
+__global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int N, int K, const bf16_t* __restrict__ A, long long sam, long long sak,
+                                                       const bf16_t* __restrict__ B, long long sbk, long long sbn,
+                                                       void* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                       const void* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
+                                                       float* __restrict__ part, float* __restrict__ rs_part, int dt,
+                                                       const float* cin, long long ldcin) {
+    __shared__ __attribute__((aligned(16))) unsigned short tiles[2][TB][BPITCH];
+    unsigned short (*As)[BPITCH] = tiles[0], (*Bs)[BPITCH] = tiles[1];
     float rs = 0.0f;
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6, wm = (wv >> 1) * 64, wn = (wv & 1) * 64, li = lane & 31, kh = lane >> 5;
@@ -372,15 +397,15 @@ __global__ __launch_bounds__(256) void bgemm128_kernel(int M, int N, int K, cons
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float4 va[4], vb[4];
-    btile_fetch<A_KCONT>(va, A, sam, sak, m0, M, k0, k1, t);
-    btile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, k0, k1, t);
+    uint4 ha[4], hb[4];
+    btile_fetch_h<A_KCONT>(ha, A, sam, sak, m0, M, k0, k1, t);
+    btile_fetch_h<B_KCONT>(hb, B, sbn, sbk, n0, N, k0, k1, t);
     for (int kb = k0; kb < k1; kb += BK) {
-        btile_store<A_KCONT>(As, va, t);
-        btile_store<B_KCONT>(Bs, vb, t);
+        btile_store_h<A_KCONT>(As, ha, t);
+        btile_store_h<B_KCONT>(Bs, hb, t);
         __syncthreads();
-        btile_fetch<A_KCONT>(va, A, sam, sak, m0, M, kb + BK, k1, t);       // (all zeros past the end)
-        btile_fetch<B_KCONT>(vb, B, sbn, sbk, n0, N, kb + BK, k1, t);
+        btile_fetch_h<A_KCONT>(ha, A, sam, sak, m0, M, kb + BK, k1, t);     // (all zeros past the end)
+        btile_fetch_h<B_KCONT>(hb, B, sbn, sbk, n0, N, kb + BK, k1, t);
         if (!A_KCONT && rowsum && (unsigned)((kb - k0) / BK) % gridDim.x == blockIdx.x && t < TB) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += __builtin_bit_cast(float, (unsigned)As[t][kk] << 16);
@@ -398,6 +423,53 @@ __global__ __launch_bounds__(256) void bgemm128_kernel(int M, int N, int K, cons
         }
         __syncthreads();
     }
+    // bf16 result (and mask) with 16-byte rows: the tile leaves through LDS -- the two 64-row halves one after the other in the
+    // operand tiles' space -- so that every lane moves 16 contiguous bytes of a row (the register layout of the accumulators
+    // would store 2 bytes per lane: 64 store instructions and, with a mask, 64 loads per thread)
+    const bool vec = nz == 1 && (dt & DT_C) && ldc % 8 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 && n0 + TB <= N &&
+                     (!mask || ((dt & DT_M) && ldm % 8 == 0 && reinterpret_cast<uintptr_t>(mask) % 16 == 0));
+    if (vec) {
+        constexpr int SP = TB + 8;                                      // staging pitch (bf16 elements): 272-byte rows
+        static_assert(64 * SP * 2 <= (int)sizeof(tiles), "a half tile fits the operand tiles' space");
+        bf16_t* stage = &tiles[0][0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wn + 32 * j + li;
+                const float bv = bias ? bias[n0 + nl] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (wv >> 1) * 32 + rho(r, kh), m = m0 + wm + 32 * i + rho(r, kh);
+                    float v = acc[i][j][r];
+                    if ((flags & GEMM_ACC) && m < M) v += cin[(long long)m * ldcin + n0 + nl];
+                    v += bv;
+                    if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
+                    stage[ml * SP + nl] = f2bf(v);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                               // 64 rows x 16 chunks of 16 bytes
+                const int idx = t + 256 * q, ml = idx >> 4, ch = idx & 15;
+                const int m = m0 + (ml >> 5) * 64 + 32 * i + (ml & 31);
+                if (m >= M) continue;
+                uint4 v = *reinterpret_cast<const uint4*>(stage + ml * SP + ch * 8);
+                if (mask) {
+                    const uint4 k = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(mask) + (long long)m * ldm + n0 + ch * 8);
+                    // keep where the stored post-activation is > 0: a positive bf16 has its sign bit clear and is not zero
+                    auto keep = [](unsigned x, unsigned kk) {
+                        const unsigned lo = ((kk & 0x8000u) == 0u && (kk & 0x7fffu) != 0u) ? 0xffffu : 0u;
+                        const unsigned hi = ((kk & 0x80000000u) == 0u && (kk & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+                        return x & (lo | hi);
+                    };
+                    v = make_uint4(keep(v.x, k.x), keep(v.y, k.y), keep(v.z, k.z), keep(v.w, k.w));
+                }
+                *reinterpret_cast<uint4*>(static_cast<bf16_t*>(C) + (long long)m * ldc + n0 + ch * 8) = v;
+            }
+            __syncthreads();
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn + 32 * j + li;
@@ -409,23 +481,137 @@ __global__ __launch_bounds__(256) void bgemm128_kernel(int M, int N, int K, cons
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * i + rho(r, kh);
                 if (m >= M) continue;
-                float* c = C + (long long)m * ldc + n;
                 float v = acc[i][j][r];
                 if (nz > 1) { part[((long long)blockIdx.z * M + m) * N + n] = v; continue; }
-                if (flags & GEMM_ACC) v += *c;
+                if (flags & GEMM_ACC) v += cin[(long long)m * ldcin + n];
                 v += bv;
                 if (flags & GEMM_RELU) v = fmaxf(v, 0.0f);
-                if (mask && !(mask[(long long)m * ldm + n] > 0.0f)) v = 0.0f;
-                *c = v;
+                if (mask && !(ld_el(mask, (long long)m * ldm + n, dt & DT_M) > 0.0f)) v = 0.0f;
+                st_el(C, (long long)m * ldc + n, v, dt & DT_C);
             }
     }
+    }
     if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
+}
+
+// ---- the heads' skinny products (alpha: 1 output on 256 inputs, rgb: 3 on 128): one pass over the activations at memory
+// speed instead of a 64-wide GEMM tile with 1-3 useful columns.  XT = the activations' element type; a row of K elements is
+// read by LPR = K / VEC lanes, 16 bytes each (VEC = 8 bf16 or 4 floats).
+template <typename XT> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+    }
+};
+// Y[p, o] = b[o] + sum_k X[p, k] Wt[o, k], o < NO (Y fp32 with leading dimension ldy)
+template <typename XT, int NO>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const XT* __restrict__ X, long long ldx, long long P, int K, const float* __restrict__ Wt, long long ldw,
+                                                         const float* __restrict__ b, float* __restrict__ Y, long long ldy) {
+    constexpr int VEC = Vec16<XT>::N;
+    const int lpr = K / VEC, t = threadIdx.x, kl = (t % lpr) * VEC, rg = t / lpr, nrg = 256 / lpr;
+    float w[NO][VEC];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[o][e] = Wt[o * ldw + kl + e];
+    for (long long p = (long long)blockIdx.x * nrg + rg; p < P; p += (long long)gridDim.x * nrg) {
+        float x[VEC], acc[NO];
+        Vec16<XT>::load(X + p * ldx + kl, x);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            acc[o] = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[o] = fmaf(x[e], w[o][e], acc[o]);
+        }
+        for (int d = lpr >> 1; d > 0; d >>= 1)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) acc[o] += __shfl_xor(acc[o], d);
+        if (t % lpr == 0)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) Y[p * ldy + o] = acc[o] + (b ? b[o] : 0.0f);
+    }
+}
+// part[block][o][k] = sum over the block's points of dY[p, o] X[p, k] (dY fp32, leading dimension ldy); reduce_parts_kernel
+// adds the blocks in order
+template <typename XT, int NO>
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const XT* __restrict__ X, long long ldx, long long P, int K, const float* __restrict__ dY, long long ldy,
+                                                        float* __restrict__ part) {
+    constexpr int VEC = Vec16<XT>::N;
+    __shared__ float red[256][NO * VEC + 1];
+    const int lpr = K / VEC, t = threadIdx.x, kl = (t % lpr) * VEC, rg = t / lpr, nrg = 256 / lpr;
+    const long long per = (P + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * per, p1 = min(P, p0 + per);
+    float acc[NO][VEC];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[o][e] = 0.0f;
+    for (long long p = p0 + rg; p < p1; p += nrg) {
+        float x[VEC];
+        Vec16<XT>::load(X + p * ldx + kl, x);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float g = dY[p * ldy + o];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[o][e] = fmaf(g, x[e], acc[o][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[t][o * VEC + e] = acc[o][e];
+    __syncthreads();
+    for (int i = t; i < NO * K; i += 256) {             // element (o, k): the row groups' shares, in order
+        const int o = i / K, k = i - o * K, lane = k / VEC, e = k - lane * VEC;
+        float sum = 0.0f;
+        for (int g = 0; g < nrg; ++g) sum += red[g * lpr + lane][o * VEC + e];
+        part[(long long)blockIdx.x * NO * K + i] = sum;
+    }
 }
 
 // out[i (row-major M x N with leading dimension ldo)] = sum over the nz slices of part[z][M][N], in slice order
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nz, int M, int N,
                                                           float* __restrict__ out, long long ldo) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x, MN = (long long)M * N;
+    const long long MN = (long long)M * N;
+    if (N % 4 == 0 && ldo % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && nz >= 8) {
+        // four elements per thread; the slices in four consecutive groups, one per wave of the block, each summed in slice
+        // order, the four group sums added in a fixed order (bitwise repeatable like the plain loop, four times the loads in
+        // flight, four times the blocks)
+        __shared__ float4 red[4][64];
+        const int e = threadIdx.x & 63, zg = threadIdx.x >> 6;
+        const long long i = (blockIdx.x * 64ll + e) * 4;
+        const int zper = (nz + 3) / 4, z0 = zg * zper, z1 = min(nz, z0 + zper);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < MN) {
+            int z = z0;
+            for (; z + 4 <= z1; z += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(part + z * MN + i), b = *reinterpret_cast<const float4*>(part + (z + 1) * MN + i);
+                const float4 c = *reinterpret_cast<const float4*>(part + (z + 2) * MN + i), d = *reinterpret_cast<const float4*>(part + (z + 3) * MN + i);
+                s.x = ((s.x + a.x) + b.x) + c.x + d.x; s.y = ((s.y + a.y) + b.y) + c.y + d.y;
+                s.z = ((s.z + a.z) + b.z) + c.z + d.z; s.w = ((s.w + a.w) + b.w) + c.w + d.w;
+            }
+            for (; z < z1; ++z) {
+                const float4 a = *reinterpret_cast<const float4*>(part + z * MN + i);
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+        }
+        red[zg][e] = s;
+        __syncthreads();
+        if (zg == 0 && i < MN) {
+            const float4 a = red[0][e], b = red[1][e], c = red[2][e], d = red[3][e];
+            const float4 r = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            *reinterpret_cast<float4*>(out + (i / N) * ldo + (i % N)) = r;
+        }
+        return;
+    }
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= MN) return;
     float s = 0.0f;
     for (int z = 0; z < nz; ++z) s += part[z * MN + i];
@@ -433,18 +619,23 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 }
 
 // dH <- dH where H > 0 else 0 (ReLU backward on the stored post-activation)
-__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d, const float* __restrict__ h, long long count) {
+__global__ __launch_bounds__(256) void relu_mask_kernel(void* __restrict__ d, const void* __restrict__ h, long long count, int bf) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
-        if (!(h[i] > 0.0f)) d[i] = 0.0f;
+        if (!(ld_el(h, i, bf) > 0.0f)) st_el(d, i, 0.0f, bf);
+}
+
+// the 16-bit mode's copy of a weight matrix (rounded once per step, read by every tile of the step's GEMMs)
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long count) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
 
 // part[block][n] = sum over the block's 256 rows of d[row * ld + n] (bias gradients; reduce_parts_kernel adds the
 // blocks in order)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part, int bf) {
     const long long r0 = blockIdx.x * 256ll, r1 = min(rows, r0 + 256);
     for (int n = threadIdx.x; n < N; n += 256) {
         float s = 0.0f;
-        for (long long r = r0; r < r1; ++r) s += d[r * ld + n];
+        for (long long r = r0; r < r1; ++r) s += ld_el(d, r * ld + n, bf);
         part[(long long)blockIdx.x * N + n] = s;
     }
 }
@@ -543,7 +734,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const float* __restri
 struct Pass {               // one network evaluation kept for the backward pass
     long long P = 0;        // points
     int S = 0;
-    float *X = nullptr, *H[DEPTH] = {}, *F = nullptr, *G = nullptr, *raw = nullptr, *z = nullptr, *noise = nullptr, *pn = nullptr;
+    void *X = nullptr, *H[DEPTH] = {}, *F = nullptr, *G = nullptr;       // tape element type: fp32, or bf16 in the 16-bit mode
+    float *raw = nullptr, *z = nullptr, *noise = nullptr, *pn = nullptr;
 };
 
 struct Tape {
@@ -554,13 +746,18 @@ struct Tape {
     long long n = 0;
     int S = 0, N = 0, fc = 0;
     float *rays = nullptr, *cams = nullptr;
-    float *tmpA = nullptr, *tmpB = nullptr, *dG = nullptr, *dC = nullptr, *d_raw = nullptr;
+    void *tmpA = nullptr, *tmpB = nullptr, *dG = nullptr;       // activation gradients (tape element type)
+    bf16_t* wb[2][24] = {};                                     // 16-bit mode: bf16 copies of the weight matrices (even tensor indices)
+    float *tmpF = nullptr;                                      // 16-bit mode: fp32 partial sums of the two-part layers (skip layer, view layer, dH7)
+    float *dC = nullptr, *d_raw = nullptr;
     float *part = nullptr, *rs_part = nullptr, *ray_g = nullptr;      // split-K slices, row / column sum shares, per-ray code gradients
     Pass pass[2];
     pg_net_params params[2];
     bool has_fine = false;
-    bool bf16 = false;          // 16-bit training mode (handle precision PG_PREC_BF16): bf16 operands in the large GEMMs
+    bool bf16 = false;          // 16-bit training mode (handle precision PG_PREC_BF16): bf16 tape, bf16 operands in the large GEMMs
+    int es() const { return bf16 ? 2 : 4; }                     // bytes per tape element
 };
+inline const void* el_off(const void* p, long long elems, int es) { return static_cast<const uint8_t*>(p) + elems * es; }
 
 constexpr size_t PART_FLOATS = 20u << 20;        // split-K scratch: slices x M x N of the largest weight gradient (80 MB)
 constexpr size_t RS_FLOATS = 1u << 20;
@@ -577,62 +774,87 @@ inline Tape* tape_of(pg_handle* h) {
     } while (0)
 
 // C[M,N] = A B (+ bias, relu, accumulate); ksplit > 1: K in slices, summed into C in slice order (C is overwritten)
-int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const float* A, long long sam, long long sak,
-         const float* B, long long sbk, long long sbn, float* C, long long ldc, const float* bias, int flags, int ksplit = 1,
-         const float* mask = nullptr, long long ldm = 0, float* rowsum = nullptr) {
+// dt (DT_*): which of A, B, C and the mask are bf16 arrays (16-bit mode: the tape's activations); GEMM_ACC adds cin (fp32,
+// leading dimension ldcin; null: C itself, fp32)
+int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const void* A, long long sam, long long sak,
+         const void* B, long long sbk, long long sbn, void* C, long long ldc, const float* bias, int flags, int ksplit = 1,
+         const void* mask = nullptr, long long ldm = 0, float* rowsum = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
     Tape& t = *tape_of(h);
+    if ((flags & GEMM_ACC) && !cin) {
+        if (dt & DT_C) return pg_fail(h, PG_EINVAL, "accumulating GEMM into a bf16 result needs an fp32 input array");
+        cin = static_cast<const float*>(C); ldcin = ldc;
+    }
     if (ksplit > 1) {
         const long long fit = (long long)(PART_FLOATS / ((size_t)M * N));
         if (fit < 2) return pg_fail(h, PG_EINVAL, "split-K scratch too small for a %d x %d result", M, N);
         if (ksplit > fit) ksplit = (int)fit;
         if (!t.part) return pg_fail(h, PG_ESTATE, "split-K GEMM without a tape");
+        if (dt & DT_C) return pg_fail(h, PG_EINVAL, "split-K GEMM results are fp32");
     }
     auto reduce = [&](const float* part, int nz, int rows, int cols, float* out, long long ldo) {
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)(((long long)rows * cols + 255) / 256)), dim3(256), 0, s, part, nz, rows, cols, out, ldo);
     };
-    auto al4 = [](const void* p, long long a, long long b) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && a % 4 == 0 && b % 4 == 0; };
-    // (the strides that are not 1 must keep 16-byte alignment of every row / k start; M, N, K multiples of 4)
-    const bool big = M >= 64 && N >= 64 && M % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
-                     al4(A, a_kcont ? sam : sak, 4) && al4(B, b_kcont ? sbn : sbk, 4);
+    // 16-byte loads: the contiguous index in runs of 4 floats / 8 bf16, every other stride and the base aligned likewise
+    auto aligned = [](const void* p, long long stride, bool bf) { return reinterpret_cast<uintptr_t>(p) % 16 == 0 && stride % (bf ? 8 : 4) == 0; };
+    const bool abf = dt & DT_A, bbf = dt & DT_B;
+    const int qa = abf ? 8 : 4, qb = bbf ? 8 : 4;
+    bool big = M >= 64 && N >= 64 && aligned(A, a_kcont ? sam : sak, abf) && aligned(B, b_kcont ? sbn : sbk, bbf) &&
+               (a_kcont ? K % qa == 0 : M % qa == 0) && (b_kcont ? K % qb == 0 : N % qb == 0);
+    if ((abf || bbf) && !t.bf16) return pg_fail(h, PG_EINVAL, "bf16 GEMM operands outside the 16-bit mode");
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
         if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
-#define PG_GEMM128(KERNEL, AK, BK_) hipLaunchKernelGGL((KERNEL<AK, BK_>), g, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part)
-        if (t.bf16) {
-            if (a_kcont && b_kcont) PG_GEMM128(bgemm128_kernel, true, true);
-            else if (a_kcont) PG_GEMM128(bgemm128_kernel, true, false);
-            else PG_GEMM128(bgemm128_kernel, false, false);
+        bool launched = true;
+#define PG_BGEMM(AK, BK_) hipLaunchKernelGGL((bgemm128_kernel<AK, BK_>), g, dim3(256), 0, s, M, N, K, static_cast<const bf16_t*>(A), sam, sak, static_cast<const bf16_t*>(B), sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part, dt, cin, ldcin)
+        if (t.bf16) {       // the operand layouts the 16-bit training step uses: forward, dX, dW
+            if (!(abf && bbf)) launched = false;
+            else if (a_kcont && b_kcont) PG_BGEMM(true, true);
+            else if (a_kcont) PG_BGEMM(true, false);
+            else PG_BGEMM(false, false);
         } else {
-            if (a_kcont && b_kcont) PG_GEMM128(sgemm128_kernel, true, true);
-            else if (a_kcont) PG_GEMM128(sgemm128_kernel, true, false);
-            else PG_GEMM128(sgemm128_kernel, false, false);
+            if (dt) return pg_fail(h, PG_EINVAL, "bf16 GEMM operands outside the 16-bit mode");
+            float* Cf = static_cast<float*>(C);
+            const float* Af = static_cast<const float*>(A);
+            const float* Bf = static_cast<const float*>(B);
+            const float* mf = static_cast<const float*>(mask);
+#define PG_SGEMM(AK, BK_) hipLaunchKernelGGL((sgemm128_kernel<AK, BK_>), g, dim3(256), 0, s, M, N, K, Af, sam, sak, Bf, sbk, sbn, Cf, ldc, bias, flags, mf, ldm, rowsum, t.part, t.rs_part, cin, ldcin)
+            if (a_kcont && b_kcont) PG_SGEMM(true, true);
+            else if (a_kcont) PG_SGEMM(true, false);
+            else PG_SGEMM(false, false);
+#undef PG_SGEMM
         }
-#undef PG_GEMM128
-        PG_LAUNCH_CHECK(h, "gemm128");
-        if (ksplit > 1) { reduce(t.part, ksplit, M, N, C, ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
-        if (rowsum && !a_kcont) { reduce(t.rs_part, ksplit * (int)g.x, M, 1, rowsum, 1); PG_LAUNCH_CHECK(h, "row-sum reduction"); }
-        return PG_OK;
+#undef PG_BGEMM
+        if (launched) {
+            PG_LAUNCH_CHECK(h, "gemm128");
+            if (ksplit > 1) { reduce(t.part, ksplit, M, N, static_cast<float*>(C), ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
+            if (rowsum && !a_kcont) { reduce(t.rs_part, ksplit * (int)g.x, 1, M, rowsum, M); PG_LAUNCH_CHECK(h, "row-sum reduction"); }
+            return PG_OK;
+        }
     }
-    // small or unaligned shapes: the 64-tile kernel, then the mask / the row sums as kernels of their own
-    if (mask && (ldc != N || ldm != N)) return pg_fail(h, PG_EINVAL, "ReLU mask behind a strided GEMM result is not supported");
+    // small or unaligned shapes (and operand type mixes the 128-tile kernel has no instantiation for): the 64-tile kernel,
+    // then the mask / the row sums as kernels of their own
+    if (mask && (ldc != N || ldm != N || ((dt & DT_C) != 0) != ((dt & DT_M) != 0)))
+        return pg_fail(h, PG_EINVAL, "ReLU mask behind a strided small GEMM result is not supported");
     if (rowsum && a_kcont) return pg_fail(h, PG_EINVAL, "row sums need the m-contiguous A operand");
     const dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, ksplit);
-    if (a_kcont && b_kcont) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
-    else if (a_kcont) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
-    else if (!b_kcont) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part);
+#define PG_SMALL(AK, BK_) hipLaunchKernelGGL((sgemm_kernel<AK, BK_>), grid, dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, bias, flags, t.part, dt, cin, ldcin)
+    if (a_kcont && b_kcont) PG_SMALL(true, true);
+    else if (a_kcont) PG_SMALL(true, false);
+    else if (!b_kcont) PG_SMALL(false, false);
     else return pg_fail(h, PG_EINVAL, "unsupported GEMM operand layout");
+#undef PG_SMALL
     PG_LAUNCH_CHECK(h, "sgemm");
-    if (ksplit > 1) { reduce(t.part, ksplit, M, N, C, ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
+    if (ksplit > 1) { reduce(t.part, ksplit, M, N, static_cast<float*>(C), ldc); PG_LAUNCH_CHECK(h, "split-K reduction"); }
     if (mask) {
         const unsigned blocks = (unsigned)std::min<long long>(((long long)M * N + 255) / 256, 8192);
-        hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, C, mask, (long long)M * N);
+        hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, C, mask, (long long)M * N, (dt & DT_C) ? 1 : 0);
         PG_LAUNCH_CHECK(h, "relu_mask");
     }
     if (rowsum) {
         const unsigned blocks = (unsigned)((K + 255) / 256);
         if ((size_t)blocks * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
-        hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, (long long)K, M, sak, t.rs_part);
+        hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, (long long)K, M, sak, t.rs_part, abf ? 1 : 0);
         PG_LAUNCH_CHECK(h, "colsum");
         reduce(t.rs_part, (int)blocks, 1, M, rowsum, M);
         PG_LAUNCH_CHECK(h, "column-sum reduction");
@@ -640,39 +862,76 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
     return PG_OK;
 }
 // Y[P,out] = X[P,in] W[out,in]^T (+ b, relu, accumulate)        (nn.Linear forward)
-int linear_fwd(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* X, long long ldx, const float* W, long long ldw,
-               float* Y, long long ldy, const float* b, int flags) {
-    return gemm(h, s, true, true, (int)P, out, in, X, ldx, 1, W, 1, ldw, Y, ldy, b, flags);
+// dt: DT_A = X is bf16, DT_C = Y is bf16; cin: the fp32 array GEMM_ACC adds (null: Y itself)
+int linear_fwd(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* X, long long ldx, const void* W, long long ldw,
+               void* Y, long long ldy, const float* b, int flags, int dt = 0, const float* cin = nullptr, long long ldcin = 0) {
+    // the heads (1 or 3 outputs, fp32 weights and result): one pass over X
+    const bool xbf = dt & DT_A;
+    const int vec = xbf ? 8 : 4, lpr = in / vec;
+    if ((out == 1 || out == 3) && flags == 0 && !(dt & (DT_B | DT_C)) && in % vec == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 &&
+        ldx % vec == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0) {
+        const long long nrg = 256 / lpr;
+        const unsigned grid = (unsigned)std::min<long long>((P + nrg - 1) / nrg, 4096);
+        const float* Wf = static_cast<const float*>(W);
+        float* Yf = static_cast<float*>(Y);
+#define PG_SKF(XT, NO) hipLaunchKernelGGL((skinny_fwd_kernel<XT, NO>), dim3(grid), dim3(256), 0, s, static_cast<const XT*>(X), ldx, P, in, Wf, ldw, b, Yf, ldy)
+        if (xbf) { if (out == 1) PG_SKF(bf16_t, 1); else PG_SKF(bf16_t, 3); }
+        else { if (out == 1) PG_SKF(float, 1); else PG_SKF(float, 3); }
+#undef PG_SKF
+        PG_LAUNCH_CHECK(h, "skinny forward");
+        return PG_OK;
+    }
+    return gemm(h, s, true, true, (int)P, out, in, X, ldx, 1, W, 1, ldw, Y, ldy, b, flags, 1, nullptr, 0, nullptr, dt, cin, ldcin);
 }
 // dX[P,in] (+)= dY[P,out] W[out,in]
 // relu_of: the stored post-activation the consumer of dX was ReLU'd to -- dX is zeroed where it is <= 0 (fused ReLU backward)
-int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* W, long long ldw,
-                 float* dX, long long ldx, int flags, const float* relu_of = nullptr) {
-    return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx);
+// dt: DT_A = dY, DT_C = dX, DT_M = relu_of are bf16
+int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* dY, long long ldy, const void* W, long long ldw,
+                 void* dX, long long ldx, int flags, const void* relu_of = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0) {
+    return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
 }
-// dW[out,in] = dY[P,out]^T X[P,in] (split-K over the points, slices summed in order)
-int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, const float* dY, long long ldy, const float* X, long long ldx,
-                 float* dW, long long ldw, float* db = nullptr) {      // db[out] += column sums of dY (the bias gradient, fused)
+// dW[out,in] = dY[P,out]^T X[P,in] (split-K over the points, slices summed in order); dt: DT_A = dY, DT_B = X are bf16
+int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* dY, long long ldy, const void* X, long long ldx,
+                 float* dW, long long ldw, float* db = nullptr, int dt = 0) {      // db[out] += column sums of dY (the bias gradient, fused)
+    {   // the heads' weight gradients (1 or 3 rows, dY fp32): one pass over X, per-block shares summed in order
+        Tape& t = *tape_of(h);
+        const bool xbf = dt & DT_B;
+        const int vec = xbf ? 8 : 4, lpr = in / vec;
+        if ((out == 1 || out == 3) && !db && !(dt & DT_A) && ldw == in && in % vec == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 &&
+            ldx % vec == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 && t.part) {
+            const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(512, (P + 511) / 512));
+            if ((size_t)grid * out * in > PART_FLOATS) return pg_fail(h, PG_EINVAL, "split-K scratch too small");
+            const float* dYf = static_cast<const float*>(dY);
+#define PG_SKW(XT, NO) hipLaunchKernelGGL((skinny_dw_kernel<XT, NO>), dim3(grid), dim3(256), 0, s, static_cast<const XT*>(X), ldx, P, in, dYf, ldy, t.part)
+            if (xbf) { if (out == 1) PG_SKW(bf16_t, 1); else PG_SKW(bf16_t, 3); }
+            else { if (out == 1) PG_SKW(float, 1); else PG_SKW(float, 3); }
+#undef PG_SKW
+            PG_LAUNCH_CHECK(h, "skinny weight gradient");
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((out * in + 255) / 256)), dim3(256), 0, s, t.part, (int)grid, out, in, dW, ldw);
+            PG_LAUNCH_CHECK(h, "skinny weight gradient reduction");
+            return PG_OK;
+        }
+    }
     const int tb = (out >= 64 && in >= 64) ? TB : GB;            // the tile gemm() will pick
     const int tiles = ((out + tb - 1) / tb) * ((in + tb - 1) / tb);
     // about one workgroup per CU (the GEMM streams dY and X once whatever the split): every slice costs a tile of partial
     // sums written and read again by the reduction
     int ksplit = (int)std::max<long long>(1, std::min<long long>(256 / std::max(tiles, 1), (P + 2047) / 2048));
-    return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2), nullptr, 0, db);
+    return gemm(h, s, false, false, out, in, (int)P, dY, 1, ldy, X, ldx, 1, dW, ldw, nullptr, 0, std::max(ksplit, 2), nullptr, 0, db, dt);
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
     Tape& t = *tape_of(h);
     const unsigned blocks = (unsigned)((rows + 255) / 256);
     if ((size_t)blocks * N > RS_FLOATS) return pg_fail(h, PG_EINVAL, "column-sum scratch too small");
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, d, rows, N, ld, t.rs_part);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, d, rows, N, ld, t.rs_part, 0);
     PG_LAUNCH_CHECK(h, "colsum");
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, t.rs_part, (int)blocks, 1, N, out, (long long)N);
     PG_LAUNCH_CHECK(h, "column-sum reduction");
     return PG_OK;
 }
-int relu_mask(pg_handle* h, hipStream_t s, float* d, const float* hh, long long count) {
+int relu_mask(pg_handle* h, hipStream_t s, void* d, const void* hh, long long count, int bf) {
     const unsigned blocks = (unsigned)std::min<long long>((count + 255) / 256, 8192);
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, d, hh, count);
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, s, d, hh, count, bf);
     PG_LAUNCH_CHECK(h, "relu_mask");
     return PG_OK;
 }
@@ -680,30 +939,47 @@ int relu_mask(pg_handle* h, hipStream_t s, float* d, const float* hh, long long 
 #define PG_TRY(call) do { const int rc_ = (call); if (rc_) return rc_; } while (0)
 
 // tensor i of a net in pg_load_weights order: 2l / 2l+1 = pts_linears.l.{weight,bias}; 16,17 alpha; 18,19 feature; 20,21 views; 22,23 rgb
-int mlp_forward(pg_handle* h, hipStream_t s, const Pass& p, const pg_net_params& w, int fc) {
+// 16-bit mode: every activation of the tape is a bf16 array (A = DT_A, results DT_C); a layer made of two GEMMs (the skip
+// layer, the view layer) sums in the fp32 array tmpF and rounds once
+int mlp_forward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, const pg_net_params& w, int fc) {
     const long long P = p.P;
     const int vk = CH_D + (fc ? FC_CH : 0), vcols = W + vk;
-    PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, w.w[0], CH_X, p.H[0], W, w.w[1], GEMM_RELU));
+    const int bf = t.bf16 ? 1 : 0, es = t.es();
+    const int ABC = bf ? (DT_A | DT_B | DT_C) : 0, AB = bf ? (DT_A | DT_B) : 0, A_ = bf ? DT_A : 0;
+    // weight matrix i from column `off` on: the step's bf16 copy in the 16-bit mode (large GEMMs only)
+    auto WT = [&](int i, long long off) -> const void* {
+        return bf ? static_cast<const void*>(t.wb[net][i] + off) : static_cast<const void*>(w.w[i] + off);
+    };
+    PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, WT(0, 0), CH_X, p.H[0], W, w.w[1], GEMM_RELU, ABC));
     for (int l = 1; l < DEPTH; ++l) {
         if (l == SKIP + 1) {        // h = cat([x, h]) in front of layer 5 (nerf.py:99-101)
-            PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, w.w[2 * l], CH_X + W, p.H[l], W, nullptr, 0));
-            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, w.w[2 * l] + CH_X, CH_X + W, p.H[l], W, w.w[2 * l + 1], GEMM_ACC | GEMM_RELU));
+            void* part = bf ? static_cast<void*>(t.tmpF) : p.H[l];
+            PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, WT(2 * l, 0), CH_X + W, part, W, nullptr, 0, AB));
+            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, CH_X), CH_X + W, p.H[l], W, w.w[2 * l + 1], GEMM_ACC | GEMM_RELU, ABC,
+                              static_cast<const float*>(part), W));
         } else {
-            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, w.w[2 * l], W, p.H[l], W, w.w[2 * l + 1], GEMM_RELU));
+            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, 0), W, p.H[l], W, w.w[2 * l + 1], GEMM_RELU, ABC));
         }
     }
-    const float* h7 = p.H[DEPTH - 1];
-    PG_TRY(linear_fwd(h, s, P, 1, W, h7, W, w.w[16], W, p.raw + 3, 4, w.w[17], 0));
-    PG_TRY(linear_fwd(h, s, P, W, W, h7, W, w.w[18], W, p.F, W, w.w[19], 0));
-    PG_TRY(linear_fwd(h, s, P, VW, W, p.F, W, w.w[20], vcols, p.G, VW, nullptr, 0));
-    PG_TRY(linear_fwd(h, s, P, VW, vk, p.X + CH_X, XW, w.w[20] + W, vcols, p.G, VW, w.w[21], GEMM_ACC | GEMM_RELU));
-    PG_TRY(linear_fwd(h, s, P, 3, VW, p.G, VW, w.w[22], VW, p.raw, 4, w.w[23], 0));
+    const void* h7 = p.H[DEPTH - 1];
+    PG_TRY(linear_fwd(h, s, P, 1, W, h7, W, w.w[16], W, p.raw + 3, 4, w.w[17], 0, A_));
+    PG_TRY(linear_fwd(h, s, P, W, W, h7, W, WT(18, 0), W, p.F, W, w.w[19], 0, ABC));
+    void* gpart = bf ? static_cast<void*>(t.tmpF) : p.G;
+    PG_TRY(linear_fwd(h, s, P, VW, W, p.F, W, WT(20, 0), vcols, gpart, VW, nullptr, 0, AB));
+    PG_TRY(linear_fwd(h, s, P, VW, vk, el_off(p.X, CH_X, es), XW, WT(20, W), vcols, p.G, VW, w.w[21], GEMM_ACC | GEMM_RELU, ABC,
+                      static_cast<const float*>(gpart), VW));
+    PG_TRY(linear_fwd(h, s, P, 3, VW, p.G, VW, w.w[22], VW, p.raw, 4, w.w[23], 0, A_));
     return PG_OK;
 }
 
-int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, const Pass& p, const pg_net_params& w, const pg_net_grads& g) {
+int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, const pg_net_params& w, const pg_net_grads& g) {
     const long long P = p.P;
     const int fc = t.fc, vk = CH_D + (fc ? FC_CH : 0), vcols = W + vk;
+    const int bf = t.bf16 ? 1 : 0, es = t.es();
+    const int A_ = bf ? DT_A : 0, B_ = bf ? DT_B : 0, C_ = bf ? DT_C : 0, AB = A_ | B_, ABC = AB | C_, ABCM = bf ? (DT_A | DT_B | DT_C | DT_M) : 0;
+    auto WT = [&](int i, long long off) -> const void* {        // (see mlp_forward)
+        return bf ? static_cast<const void*>(t.wb[net][i] + off) : static_cast<const void*>(w.w[i] + off);
+    };
     const size_t sizes[24] = {(size_t)W * CH_X, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * (CH_X + W), W,
                               (size_t)W * W, W, (size_t)W * W, W, W, 1, (size_t)W * W, W, (size_t)VW * vcols, VW, 3 * VW, 3};
     for (int i = 0; i < 24; ++i) {
@@ -711,47 +987,48 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, const Pass& p, const pg_n
         PG_HIP(h, hipMemsetAsync(g.w[i], 0, sizes[i] * sizeof(float), s));
     }
     const float* d_raw = t.d_raw;
-    float* dG = t.dG;
+    void* dG = t.dG;
     // rgb_linear: raw[:, :3] = G Wr^T + br
-    PG_TRY(linear_bwd_x(h, s, P, 3, VW, d_raw, 4, w.w[22], VW, dG, VW, 0));
-    PG_TRY(linear_bwd_w(h, s, P, 3, VW, d_raw, 4, p.G, VW, g.w[22], VW));
+    PG_TRY(linear_bwd_x(h, s, P, 3, VW, d_raw, 4, w.w[22], VW, dG, VW, 0, nullptr, C_));
+    PG_TRY(linear_bwd_w(h, s, P, 3, VW, d_raw, 4, p.G, VW, g.w[22], VW, nullptr, B_));
     PG_TRY(colsum(h, s, d_raw, P, 3, 4, g.w[23]));
-    PG_TRY(relu_mask(h, s, dG, p.G, P * VW));
+    PG_TRY(relu_mask(h, s, dG, p.G, P * VW, bf));
     // views_linears.0 on [feature | view embedding (| frame code)]
-    PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols, g.w[21]));
-    PG_TRY(linear_bwd_w(h, s, P, VW, vk, dG, VW, p.X + CH_X, XW, g.w[20] + W, vcols));
-    float* dF = t.tmpA;
-    PG_TRY(linear_bwd_x(h, s, P, VW, W, dG, VW, w.w[20], vcols, dF, W, 0));
+    PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols, g.w[21], AB));
+    PG_TRY(linear_bwd_w(h, s, P, VW, vk, dG, VW, el_off(p.X, CH_X, es), XW, g.w[20] + W, vcols, nullptr, AB));
+    void* dF = t.tmpA;
+    PG_TRY(linear_bwd_x(h, s, P, VW, W, dG, VW, WT(20, 0), vcols, dF, W, 0, nullptr, ABC));
     if (fc && g.codes) {
         PG_HIP(h, hipMemsetAsync(g.codes, 0, (size_t)w.n_codes * FC_CH * sizeof(float), s));
-        PG_TRY(linear_bwd_x(h, s, P, VW, FC_CH, dG, VW, w.w[20] + W + CH_D, vcols, t.dC, FC_CH, 0));
+        PG_TRY(linear_bwd_x(h, s, P, VW, FC_CH, dG, VW, w.w[20] + W + CH_D, vcols, t.dC, FC_CH, 0, nullptr, A_));
         hipLaunchKernelGGL(code_ray_sum_kernel, dim3((unsigned)((t.n * FC_CH + 255) / 256)), dim3(256), 0, s, t.dC, (long long)t.n, p.S, t.ray_g);
         PG_LAUNCH_CHECK(h, "code_ray_sum");
         hipLaunchKernelGGL(code_gather_kernel, dim3((unsigned)w.n_codes), dim3(64), 0, s, t.ray_g, (long long)t.n, t.cams, w.n_codes, g.codes);
         PG_LAUNCH_CHECK(h, "code_gather");
     }
     // feature_linear and alpha_linear on the trunk output
-    const float* h7 = p.H[DEPTH - 1];
-    PG_TRY(linear_bwd_w(h, s, P, W, W, dF, W, h7, W, g.w[18], W, g.w[19]));
-    float* dH = t.tmpB;             // dH7 = (alpha's part + feature's part) * [H7 > 0]: the mask rides on the second GEMM
-    PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dH, W, 0));
-    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, w.w[18], W, dH, W, GEMM_ACC, h7));
-    PG_TRY(linear_bwd_w(h, s, P, 1, W, d_raw + 3, 4, h7, W, g.w[16], W));
+    const void* h7 = p.H[DEPTH - 1];
+    PG_TRY(linear_bwd_w(h, s, P, W, W, dF, W, h7, W, g.w[18], W, g.w[19], AB));
+    void* dH = t.tmpB;              // dH7 = (alpha's part + feature's part) * [H7 > 0]: the mask rides on the second GEMM
+    void* dpart = bf ? static_cast<void*>(t.tmpF) : dH;      // (16-bit mode: alpha's part in fp32, rounded once with the sum)
+    PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dpart, W, 0));
+    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, GEMM_ACC, h7, ABCM, static_cast<const float*>(dpart), W));
+    PG_TRY(linear_bwd_w(h, s, P, 1, W, d_raw + 3, 4, h7, W, g.w[16], W, nullptr, B_));
     PG_TRY(colsum(h, s, d_raw + 3, P, 1, 4, g.w[17]));
     // the trunk, back to front: dZ_l = dH_l * [H_l > 0]
-    float* other = t.tmpA;
+    void* other = t.tmpA;
     // (dH arrives masked: the GEMM that produced it zeroed it where H_l <= 0; the bias gradient rides on a weight-gradient GEMM)
     for (int l = DEPTH - 1; l >= 0; --l) {
         if (l == 0) {
-            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[0], CH_X, g.w[1]));
+            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[0], CH_X, g.w[1], AB));
         } else if (l == SKIP + 1) {
-            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[2 * l], CH_X + W, g.w[2 * l + 1]));
-            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l] + CH_X, CH_X + W));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l] + CH_X, CH_X + W, other, W, 0, p.H[l - 1]));
+            PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[2 * l], CH_X + W, g.w[2 * l + 1], AB));
+            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l] + CH_X, CH_X + W, nullptr, AB));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, CH_X), CH_X + W, other, W, 0, p.H[l - 1], ABCM));
             std::swap(dH, other);
         } else {
-            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l], W, g.w[2 * l + 1]));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, w.w[2 * l], W, other, W, 0, p.H[l - 1]));
+            PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l], W, g.w[2 * l + 1], AB));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, 0), W, other, W, 0, p.H[l - 1], ABCM));
             std::swap(dH, other);
         }
     }
@@ -799,12 +1076,18 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     const long long Pc = n * S, Pf = N > 0 ? n * SF : 0, Pm = std::max(Pc, Pf);
     const bool rnoise = dr && dr->ray_noise;
     size_t need = al((size_t)n * 44) + al((size_t)n * 4) + al((size_t)n * 8) + al((size_t)n * S * 4) /*w0*/ + al((size_t)n * SF * 4) /*order*/;
+    const bool bf = h->cfg.precision == PG_PREC_BF16;       // 16-bit mode: the tape's activations and their gradients are bf16 arrays
+    const size_t es = bf ? 2 : 4;
     auto pass_bytes = [&](long long P) {
-        return al((size_t)P * XW * 4) + (DEPTH + 1) * al((size_t)P * W * 4) + al((size_t)P * VW * 4) + al((size_t)P * 16) + 2 * al((size_t)P * 4) + al((size_t)P * 12);
+        return al((size_t)P * XW * es) + (DEPTH + 1) * al((size_t)P * W * es) + al((size_t)P * VW * es) + al((size_t)P * 16) + 2 * al((size_t)P * 4) + al((size_t)P * 12);
     };
     need += pass_bytes(Pc) + (N > 0 ? pass_bytes(Pf) : 0);
-    need += 2 * al((size_t)Pm * W * 4) + al((size_t)Pm * VW * 4) + al((size_t)Pm * FC_CH * 4) + al((size_t)Pm * 16);
+    need += 2 * al((size_t)Pm * W * es) + al((size_t)Pm * VW * es) + al((size_t)Pm * FC_CH * 4) + al((size_t)Pm * 16) + (bf ? al((size_t)Pm * W * 4) : 0);
     need += al(PART_FLOATS * 4) + al(RS_FLOATS * 4) + al((size_t)n * FC_CH * 4);
+    const int vcols_ = W + CH_D + (fc ? FC_CH : 0);
+    const size_t wsize[24] = {(size_t)W * CH_X, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * (CH_X + W), 0,
+                              (size_t)W * W, 0, (size_t)W * W, 0, 0, 0, (size_t)W * W, 0, (size_t)VW * vcols_, 0, 0, 0};     // the large GEMMs' weight matrices
+    if (bf) for (int i = 0; i < 24; ++i) need += 2 * al(wsize[i] * 2);
     if (need > t.bytes) {
         if (t.buf) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(t.buf)); t.buf = nullptr; t.bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.buf), need);
@@ -814,7 +1097,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     uint8_t* q = t.buf;
     auto take = [&](size_t b) { float* r = reinterpret_cast<float*>(q); q += al(b); return r; };
     t.n = n; t.S = S; t.N = N; t.fc = fc; t.has_fine = N > 0;
-    t.bf16 = h->cfg.precision == PG_PREC_BF16;
+    t.bf16 = bf;
     t.rays = take((size_t)n * 44);
     t.cams = cams ? take((size_t)n * 4) : (take((size_t)n * 4), nullptr);
     float* nf = take((size_t)n * 8);
@@ -825,17 +1108,28 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
         p = Pass();
         if (k == 1 && N == 0) break;
         p.P = k ? Pf : Pc; p.S = k ? SF : S;
-        p.X = take((size_t)p.P * XW * 4);
-        for (int l = 0; l < DEPTH; ++l) p.H[l] = take((size_t)p.P * W * 4);
-        p.F = take((size_t)p.P * W * 4);
-        p.G = take((size_t)p.P * VW * 4);
+        p.X = take((size_t)p.P * XW * es);
+        for (int l = 0; l < DEPTH; ++l) p.H[l] = take((size_t)p.P * W * es);
+        p.F = take((size_t)p.P * W * es);
+        p.G = take((size_t)p.P * VW * es);
         p.raw = take((size_t)p.P * 16);
         p.z = take((size_t)p.P * 4);
         p.noise = take((size_t)p.P * 4);
         p.pn = take((size_t)p.P * 12);
     }
-    t.tmpA = take((size_t)Pm * W * 4); t.tmpB = take((size_t)Pm * W * 4);
-    t.dG = take((size_t)Pm * VW * 4); t.dC = take((size_t)Pm * FC_CH * 4); t.d_raw = take((size_t)Pm * 16);
+    t.tmpA = take((size_t)Pm * W * es); t.tmpB = take((size_t)Pm * W * es);
+    t.dG = take((size_t)Pm * VW * es); t.dC = take((size_t)Pm * FC_CH * 4); t.d_raw = take((size_t)Pm * 16);
+    t.tmpF = bf ? take((size_t)Pm * W * 4) : nullptr;
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 24; ++i) t.wb[k][i] = (bf && wsize[i]) ? reinterpret_cast<bf16_t*>(take(wsize[i] * 2)) : nullptr;
+    if (bf) {       // this step's bf16 copies of the weight matrices (the parameters do not change between forward and backward)
+        for (int k = 0; k < (N > 0 ? 2 : 1); ++k)
+            for (int i = 0; i < 24; ++i) {
+                if (!wsize[i]) continue;
+                hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)((wsize[i] + 1023) / 1024)), dim3(256), 0, s, (k ? fine : coarse)->w[i], t.wb[k][i], (long long)wsize[i]);
+            }
+        PG_LAUNCH_CHECK(h, "weight conversion");
+    }
     t.part = take(PART_FLOATS * 4); t.rs_part = take(RS_FLOATS * 4); t.ray_g = take((size_t)n * FC_CH * 4);
     t.params[0] = *coarse;
     if (N > 0) t.params[1] = *fine;
@@ -856,12 +1150,15 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
         if (e) return pg_fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e));
     }
     auto embed = [&](Pass& p, const float* codes, int n_codes) {
-        hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((p.P * J + 255) / 256)), dim3(256), 0, s, t.rays, p.z, rnoise ? p.pn : nullptr, skts,
-                           (long long)pose_stride, t.cams, codes, n_codes, fc, h->d_cut, h->tau[0], h->tau[1], p.P, p.S, p.X);
+        const dim3 grid((unsigned)((p.P * J + 255) / 256));
+        if (bf) hipLaunchKernelGGL(embed_rows_kernel<bf16_t>, grid, dim3(256), 0, s, t.rays, p.z, rnoise ? p.pn : nullptr, skts, (long long)pose_stride,
+                                   t.cams, codes, n_codes, fc, h->d_cut, h->tau[0], h->tau[1], p.P, p.S, static_cast<bf16_t*>(p.X));
+        else hipLaunchKernelGGL(embed_rows_kernel<float>, grid, dim3(256), 0, s, t.rays, p.z, rnoise ? p.pn : nullptr, skts, (long long)pose_stride,
+                                t.cams, codes, n_codes, fc, h->d_cut, h->tau[0], h->tau[1], p.P, p.S, static_cast<float*>(p.X));
         return hipGetLastError();
     };
     if (embed(pc, codes_dev[0], coarse->n_codes) != hipSuccess) return pg_fail(h, PG_EHIP, "embedding kernel launch failed");
-    PG_TRY(mlp_forward(h, s, pc, *coarse, fc));
+    PG_TRY(mlp_forward(h, s, t, 0, pc, *coarse, fc));
     const bool hier = N > 0;
     e = pg_launch_composite(t.rays, pc.z, pc.raw, n, S, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, hier ? out->rgb0 : out->rgb_map,
                             hier ? out->disp0 : out->disp_map, hier ? out->acc0 : out->acc_map, hier ? out->alpha0 : out->alpha,
@@ -878,7 +1175,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
             if (e) return pg_fail(h, PG_EHIP, "noise gather launch failed: %s", hipGetErrorString((hipError_t)e));
         }
         if (embed(pf, codes_dev[1], fine->n_codes) != hipSuccess) return pg_fail(h, PG_EHIP, "embedding kernel launch failed");
-        PG_TRY(mlp_forward(h, s, pf, *fine, fc));
+        PG_TRY(mlp_forward(h, s, t, 1, pf, *fine, fc));
         e = pg_launch_composite(t.rays, pf.z, pf.raw, n, SF, h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, out->rgb_map, out->disp_map, out->acc_map,
                                 out->alpha, nullptr, 0, nullptr, pf.noise, nullptr, nullptr, stream);
         if (e) return pg_fail(h, PG_EHIP, "composite launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -914,7 +1211,7 @@ int pg_train_backward(pg_handle* h, void* stream, int64_t tape_id, const float* 
         hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((t.n + 63) / 64)), dim3(64), 0, s, t.rays, p.z, p.raw, p.noise, (long long)t.n, p.S,
                            h->cfg.density_scale, h->cfg.rgb_eps, h->cfg.density_act, h->cfg.softplus_shift, d_rgb, d_acc, t.d_raw);
         PG_LAUNCH_CHECK(h, "composite backward");
-        return mlp_backward(h, s, t, p, t.params[k], g);
+        return mlp_backward(h, s, t, k, p, t.params[k], g);
     };
     if (t.has_fine) {
         PG_TRY(run(1, d_rgb_map, d_acc_map, *fine));
