@@ -295,7 +295,7 @@ def train_step_rate(dev, n_rand=4096, steps=5, warmup=2, precision="fp32"):
             "frac": flop / (ms * 1e-3) / 1e12 / peak, "dtype": "f32" if precision == "fp32" else "bf16", "loss": float(loss.detach()),
             "what": "forward with a tape + MSE loss + loss.backward() + Adam on the whole step's wall clock, "
                     + ("fp32 (v_mfma_f32_32x32x2_f32 GEMMs)" if precision == "fp32" else
-                       "16-bit training mode (bf16 operands in the large GEMMs on v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage)")
+                       "16-bit training mode (the tape -- embedding rows, activations, their gradients -- stored in bf16, bf16 operands in the large GEMMs on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights, raw, d_raw and weight gradients fp32)")
                     + ", surreal 64+16, perturb=1, raw_noise_std=1; FLOPs = 3 x the forward MLP "
                     "FLOPs of the step's points (forward, dX and dW GEMMs); embedding and compositing not counted"}
 
