@@ -439,3 +439,23 @@ def test_box_pixel_ids_are_the_reference_valid_idxs_built_lazily():
     assert torch.equal(torch.as_tensor(c2), torch.as_tensor(cyls))
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(b2, bboxes))
     assert [m[:2] for m in meta] == [(H, W)] * 3
+
+
+def test_hazard_audit_flags_a_transcendental_result_read_by_the_next_instruction(tmp_path):
+    """tools/audit_asm_hazards.py (run by `make audit` on every fused kernel): on the gfx940 family a VALU instruction
+    may not read the result of v_sin / v_cos / v_exp / v_rcp / v_rsq / v_sqrt / v_log in the very next issue slot; hipcc
+    pads its own code but not inline asm (the first build of the compensated kernel's on-chip form read stale values in
+    the first 16 lanes that way).  The audit must fail on the adjacent pair and pass once an instruction sits in between."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "audit_asm_hazards.py")
+    head = "_Z6kernelv:\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], a[0:15]\n"
+    bad = head + "\tv_cos_f32_e32 v141, v194\n\tv_cvt_pk_f16_f32 v198, v140, v141\n\ts_endpgm\n"
+    good = head + "\tv_cos_f32_e32 v141, v194\n\ts_nop 0\n\tv_cvt_pk_f16_f32 v198, v140, v141\n\ts_endpgm\n"
+    chain = head + "\tv_rsq_f32_e32 v1, v2\n\tv_sin_f32_e32 v3, v1\n\tv_mul_f32_e32 v4, v5, v6\n\ts_endpgm\n"      # trans -> trans is not the hazard
+    wide = head + "\tv_exp_f32_e32 v9, v2\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[8:11], v[4:7], a[0:15]\n\ts_endpgm\n"  # a register range
+    for name, text, rc in (("bad", bad, 1), ("good", good, 0), ("chain", chain, 0), ("wide", wide, 1)):
+        f = tmp_path / f"{name}.s"
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert r.returncode == rc, (name, r.stdout)
