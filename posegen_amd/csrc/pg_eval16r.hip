@@ -19,6 +19,10 @@
 //     Y[ray][j] -- arrives as per-ray records computed by pg_rayrec.hip and is fetched with a few LDS-DMA pieces per
 //     pass: no table build, no Y stage, no extra barriers and no Y-stage weight traffic at the pass boundary (13 %
 //     of a pass before), and the rgb head shares the last chunk of the alpha / view segment (one chunk entry less).
+// Round 4: the joint slots are permuted into LIMBS (pg_layout.h PERM16) and the limbs a wave's points -- or a whole pass --
+// are out of cutoff range of are left out (x_segment16: wave-level skip; Stream MASK_NX: the chunk is not in the pass's
+// chunk sequence); and for one pose per call without frame codes the kernel needs no records at all (OC, the on-chip
+// variant: rows formed a pass ahead from LDS-DMA'd rays, Y by y_segment16 from limb chunks of direction weights).
 #ifndef PG_PREFETCH
 #define PG_PREFETCH 1
 #endif

@@ -27,7 +27,11 @@
 // Two forms of the view layer's direction part (template parameter REC of evalc_kernel): the direct one (per-ray
 // sin/cos table in LDS x per-point cutoff weight, 32 <= samples per ray < 64) and, for rays with >= 64 samples, the
 // record variant: per-ray (a, b) and split Y records of pg_rayrec.hip fetched by LDS-DMA, a second stage of 16-32 MFMAs
-// on the point's cutoff weights instead of 336, no table build, no divisions.
+// on the point's cutoff weights instead of 336, no table build, no divisions.  In the record variant the joint PAIRS (the
+// two lane halves' joints of a k-unit) a wave's points -- or a whole pass -- are out of cutoff range of are left out
+// (x_segment_cr, Stream MASK_NX; pg_eval16r.hip explains the test), and for one pose per call without frame codes it has
+// an on-chip form (OC) that needs no records at all: the rows are formed by the workgroup a pass ahead and the direction
+// part Y by an MFMA segment of its own (y_segment_c).
 #include <type_traits>
 
 #include "pg_eval16_common.h"

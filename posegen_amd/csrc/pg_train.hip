@@ -10,16 +10,17 @@
 // core/utils/ray_utils.py:285); poses, rays and the embedder's cutoff parameters get no gradient (the reference's
 // cutoff_dist has requires_grad=False; pose optimisation is out of scope).
 //
-// Two modes (the handle's precision): exact fp32 (below), and the 16-bit mode (PG_PREC_BF16): every activation and
-// activation gradient of the tape is STORED in bf16 (the embedding rows, the layer outputs, dH: half the bytes of a step
-// that is bound by them) and the large GEMMs multiply bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
-// weights, biases, raw, d_raw and every weight gradient stay fp32.
-// Exact fp32 arithmetic.  Training batches are small (N_rand = 2048 rays -> 131 k + 164 k points,
-// configs/surreal/surreal.txt:34), so the 1080-wide embedding and the layer activations are MATERIALISED in HBM
-// (14 KB per point, 4 GB per batch -- 1.4 % of the card) and every layer is a plain fp32 GEMM on
-// v_mfma_f32_32x32x2_f32 (128 x 128 x 16 tiles for the trunk shapes, a 64-tile kernel for the heads and unaligned
-// shapes); the weight gradients split K over the points and are reduced in a fixed order (bitwise repeatable).  The
-// fused inference kernels are not involved.
+// Training batches are small (N_rand = 2048 rays -> 131 k + 164 k points, configs/surreal/surreal.txt:34), so the
+// 1080-wide embedding and the layer activations are MATERIALISED in HBM (the tape: 14 KB per point in fp32) and every layer
+// is a plain GEMM; the weight gradients split K over the points and are reduced in a fixed order (bitwise repeatable).
+// The fused inference kernels are not involved.  Two modes, by the handle's precision:
+//   * fp32 (parity with the reference's autograd): v_mfma_f32_32x32x2_f32, 128 x 128 x 16 tiles (sgemm128_kernel), a
+//     64-tile kernel for small and unaligned shapes (sgemm_kernel);
+//   * 16-bit (PG_PREC_BF16): the tape's activations and activation gradients are STORED in bf16 (the embedding rows, the
+//     layer outputs, dH, dG) and the large GEMMs multiply bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32
+//     accumulation (bgemm128_kernel, 128 x 128 x 64 tiles; the weights as bf16 copies made once per step); weights,
+//     biases, raw, d_raw, every weight gradient and the partial sums of the two-part layers stay fp32.
+// Both: one-pass kernels for the alpha / rgb heads (skinny_fwd_kernel, skinny_dw_kernel).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
