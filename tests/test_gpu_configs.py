@@ -191,8 +191,8 @@ def test_seeded_parity_sweep():
 
 @pytest.mark.parametrize("prec,bound", [("bf16", 2e-2), ("fp16", 1e-2), ("fp16c", 1e-3)])
 def test_record_kernels_on_odd_ray_and_sample_counts(prec, bound):
-    """The per-ray-record kernels (16x16x32 for bf16 / fp16, the record variant of the compensated kernel) against the fp32
-    kernel (direct view layer, no records) on shapes that stress their pass bookkeeping: ray counts that leave the last
+    """The 16x16x32 kernel (bf16 / fp16) and the record variant of the compensated kernel, each in its on-chip form (one pose per
+    call) and its record form (the pose given per ray), against the fp32 kernel (direct view layer, no records) on shapes that stress their pass bookkeeping: ray counts that leave the last
     pass and the last record tile ragged (1 ray ... 4097 rays), sample counts that make passes straddle 2 to 5 rays at
     every offset (64 ... 200 samples), with and without importance samples.  fp32 is pinned to the reference by
     test_gpu_parity.py; the bounds are what the modes' operand precision gives on random-weight nets with importance sampling
@@ -215,14 +215,17 @@ def test_record_kernels_on_odd_ray_and_sample_counts(prec, bound):
             ref = r.render_rays(x, skts, cyl, n_samples=S, n_importance=N, want_alpha=False)
             r.set_precision(PREC_BY_NAME[prec])
             got = r.render_rays(x, skts, cyl, n_samples=S, n_importance=N, want_alpha=False)
-            for k in ("rgb_map", "acc_map"):
-                assert torch.isfinite(got[k]).all(), (n, S, N, k)
-                err = float((got[k] - ref[k]).abs().max())
-                worst = max(worst, err)
-                assert err <= bound, (prec, n, S, N, k, err)
+            # one pose per call runs the on-chip forms (no records); the same pose handed over per ray runs the record forms
+            per_ray = r.render_rays(x, skts.expand(n, -1, -1, -1).contiguous(), cyl, n_samples=S, n_importance=N, want_alpha=False)
+            for form, out in (("on-chip", got), ("records", per_ray)):
+                for k in ("rgb_map", "acc_map"):
+                    assert torch.isfinite(out[k]).all(), (form, n, S, N, k)
+                    err = float((out[k] - ref[k]).abs().max())
+                    worst = max(worst, err)
+                    assert err <= bound, (prec, form, n, S, N, k, err)
     finally:
         r.close()
-    print(f"{prec}: worst |error| vs the fp32 kernel over the odd shapes {worst:.2e}")
+    print(f"{prec}: worst |error| vs the fp32 kernel over the odd shapes, both forms {worst:.2e}")
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16c", "fp32"])
