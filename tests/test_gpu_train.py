@@ -232,8 +232,9 @@ def test_inputs_that_want_a_gradient_are_refused():
 
 @pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m"])
 def test_bf16_training_mode_gradients_are_close_and_repeatable(name):
-    """The 16-bit training mode (caster precision bf16: bf16 operands in the large forward / dX / dW GEMMs, fp32
-    accumulation, everything else fp32) against the reference's autograd: the loss within 2e-3, the norm of every
+    """The 16-bit training mode (caster precision bf16: the tape -- embedding rows, activations, activation gradients --
+    stored in bf16, bf16 operands in the large forward / dX / dW GEMMs, fp32 accumulation; weights, raw, d_raw and every
+    parameter gradient fp32) against the reference's autograd: the loss within 2e-3, the norm of every
     parameter gradient within 1e-2, every sampled entry within 0.1 of its tensor's largest entry (bounds stated: bf16
     operands carry 8 bits; measured 5e-4 on the norms, 5e-2 on single entries), and bitwise the same on a second run."""
     g = load_golden(name)
