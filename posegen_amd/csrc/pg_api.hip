@@ -318,7 +318,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fc = h->cfg.framecode_ch > 0;
     const bool onchip = sa && fact && !dbg && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
-    const bool conchip = compk && use_comp_rec(S) && (!dbg || dbg_stage == 98) && use_onchip(fc, pose_stride);   // the record variant of pg_evalc.hip without per-ray records
+    const bool conchip = compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
     const bool crec = compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec)
            : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
