@@ -149,7 +149,7 @@ template <int NS> struct PairPipe {
 __device__ __forceinline__ void retire_pair(a128& r0, a128& r1, int younger) {
     switch (younger) {   // constant after unrolling: LGKM operations younger than the pair
 #define PG_RP(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1)); break;
-        PG_RP(0) PG_RP(1) PG_RP(2) PG_RP(3) PG_RP(4) PG_RP(5) PG_RP(6) PG_RP(7) PG_RP(8)
+        PG_RP(0) PG_RP(1) PG_RP(2) PG_RP(3) PG_RP(4) PG_RP(5) PG_RP(6) PG_RP(7) PG_RP(8) PG_RP(9) PG_RP(10) PG_RP(11) PG_RP(12) PG_RP(13) PG_RP(14)
 #undef PG_RP
         default: __builtin_unreachable();
     }
