@@ -140,6 +140,11 @@ __device__ __forceinline__ VC frag_v(const unsigned* p) {
 // groups of four through the instruction's offset field (it applies to the global and the LDS
 // address alike): 2.75 instead of 6 instructions per piece.
 constexpr int PPC = CHUNK_BYTES / 2048;       // pairs per chunk
+#if defined(PG_ABL_SINGLE)
+#define PG_PL1 0
+#else
+#define PG_PL1 1
+#endif
 template <int NS> struct PairPipe {
     a128 r[NS][2];
     const uint8_t* g;      // global base of this wave's current group of four refill pieces
@@ -207,6 +212,11 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
 }
 #else
 // before the first MFMA of pair P (of a segment with TP pairs): chunk entry, and the pair must be there
+#if defined(PG_ABL_SINGLE)      // timing ablation only (wrong results): one weight plane -- half the ring reads and half the refill
+constexpr int ABL_PL = 1;
+#else
+constexpr int ABL_PL = 2;
+#endif
 template <int TP, int NS, typename ST>
 __device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
     constexpr int LA = NS - 1;
@@ -215,8 +225,8 @@ __device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
     const int rem = min(TP - 1 - P, PPC - 1);            // later pairs of this segment in this chunk
 #pragma clang loop unroll(full)
     for (int k = 0; k < LA; ++k)
-        if (k <= rem) { st.issue(p.r[(P + k) % NS][0], 2 * k); st.issue(p.r[(P + k) % NS][1], 2 * k + 1); }
-    retire_pair(p.r[P % NS][0], p.r[P % NS][1], 2 * min(LA - 1, rem));
+        if (k <= rem) { st.issue(p.r[(P + k) % NS][0], 2 * k); if (ABL_PL == 2) st.issue(p.r[(P + k) % NS][1], 2 * k + 1); }
+    retire_pair(p.r[P % NS][0], p.r[P % NS][1], ABL_PL * min(LA - 1, rem));
 }
 // between the two MFMAs of pair P: read pair P+LA, one refill piece every other pair, retire pair P+1
 template <int TP, int NS, typename ST>
@@ -224,11 +234,17 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
     constexpr int LA = NS - 1;
     const int q = P % PPC;
     const int rem = min(TP - 1 - P, PPC - 1 - q);
-    if (LA <= rem) { st.issue(p.r[(P + LA) % NS][0], 2 * (q + LA)); st.issue(p.r[(P + LA) % NS][1], 2 * (q + LA) + 1); }
+    if (LA <= rem) { st.issue(p.r[(P + LA) % NS][0], 2 * (q + LA)); if (ABL_PL == 2) st.issue(p.r[(P + LA) % NS][1], 2 * (q + LA) + 1); }
+#if defined(PG_ABL_SINGLE)
+    if ((q & 3) == 3) piece_c(p, st, q >> 2);
+    if (P == TP - 1)
+        for (int i = (q + 1) >> 2; i < ST::PER / 2; ++i) piece_c(p, st, i);
+#else
     if (q & 1) piece_c(p, st, q >> 1);
     if (P == TP - 1)            // a segment ending inside the chunk flushes the rest of the refill
         for (int i = (q + 1) >> 1; i < ST::PER; ++i) piece_c(p, st, i);
-    if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], 2 * min(LA - 1, rem - 1));
+#endif
+    if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], ABL_PL * min(LA - 1, rem - 1));
 }
 
 #endif
@@ -262,16 +278,16 @@ __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, f
                     pair_mid<TP>(p, st, P);
                     pair_begin<TP>(p, st, P + 1);
                     acc[o + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[(P + 1) % NSC][0]), frag_v(cur.x1), acc[o + 1], 0, 0, 0);
-                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(cur.x2), acc[o], 0, 0, 0);
+                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
                 } else {
                     pair_mid<TP>(p, st, P);
-                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(cur.x2), acc[o], 0, 0, 0);
+                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
                 }
             } else {
                 pair_begin<TP>(p, st, P);
                 acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(cur.x1), acc[o], 0, 0, 0);
                 pair_mid<TP>(p, st, P);
-                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(cur.x2), acc[o], 0, 0, 0);
+                acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
             }
             // second gap of the pair: one half step of the next unit's split
 #if defined(PG_ABL_NOCONV)      // timing ablation only (wrong results): the next unit's values are kept live but not split
@@ -334,7 +350,7 @@ __device__ __forceinline__ void mma_row_c(f32x16* acc, PairPipe<NSC>& p, ST& st,
         if (P == 0) hook();
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(b.x1), acc[o], 0, 0, 0);
         pair_mid<TP>(p, st, P);
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(b.x2), acc[o], 0, 0, 0);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(b.x2), acc[o], 0, 0, 0);
     }
 }
 
@@ -400,7 +416,7 @@ __device__ __forceinline__ void mma_row_cr(f32x16* acc, PairPipe<NSC>& p, ST& st
         if (o == 0 && !hooked) { hook(); hooked = true; }       // (behind the segment's first chunk entry)
         acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(b.x1), acc[o], 0, 0, 0);
         pair_mid<TP>(p, st, P);
-        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][1]), frag_v(b.x2), acc[o], 0, 0, 0);
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(b.x2), acc[o], 0, 0, 0);
     }
 }
 
