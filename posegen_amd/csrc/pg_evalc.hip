@@ -270,7 +270,8 @@ __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, f
 #pragma clang loop unroll(full)
         for (int o = 0; o < NO; ++o) {
             const int P = u * NO + o;
-            // two out tiles' pairs interleaved, so that no MFMA accumulates onto the one right before it (-0.5 %)
+            // two out tiles' pairs interleaved, so that no MFMA accumulates onto the one right before it (-0.5 %; hipcc still
+            // moves the second plane's MFMA of tile o above the first of tile o + 1 in places -- pinning the order: no change)
             if (NO % 2 == 0) {
                 if ((o & 1) == 0) {
                     pair_begin<TP>(p, st, P);
