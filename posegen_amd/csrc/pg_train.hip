@@ -376,13 +376,16 @@ __device__ __forceinline__ void btile_store_h(unsigned short (*T)[BPITCH], const
 #ifndef PG_BGEMM_WGS
 #define PG_BGEMM_WGS 3        // workgroups per CU the register budget is held to (168 VGPRs: three waves per SIMD)
 #endif
+// A second k segment of a GEMM (a layer on the concatenation of two inputs: the skip layer, the view layer): k >= K of the
+// product comes from these operands (k-contiguous both, not split over workgroups); K a multiple of the k-step
+struct KSeg2 { const bf16_t* A; const bf16_t* B; long long sam, sbn; int K; };
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int N, int K, const bf16_t* __restrict__ A, long long sam, long long sak,
                                                        const bf16_t* __restrict__ B, long long sbk, long long sbn,
                                                        void* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
                                                        const void* __restrict__ mask, long long ldm, float* __restrict__ rowsum,
                                                        float* __restrict__ part, float* __restrict__ rs_part, int dt,
-                                                       const float* cin, long long ldcin) {
+                                                       const float* cin, long long ldcin, const KSeg2 seg2) {
     __shared__ __attribute__((aligned(16))) unsigned short tiles[2][TB][BPITCH];
     unsigned short (*As)[BPITCH] = tiles[0], (*Bs)[BPITCH] = tiles[1];
     float rs = 0.0f;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
     const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
     const int nz = gridDim.z;
     const int kper = ((K + nz - 1) / nz + BK - 1) / BK * BK;
-    const int k0 = blockIdx.z * kper, k1 = min(K, k0 + kper);
+    const int k0 = blockIdx.z * kper, k1 = min(K, k0 + kper) + (A_KCONT && B_KCONT ? seg2.K : 0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -400,14 +403,21 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     uint4 ha[4], hb[4];
-    btile_fetch_h<A_KCONT>(ha, A, sam, sak, m0, M, k0, k1, t);
-    btile_fetch_h<B_KCONT>(hb, B, sbn, sbk, n0, N, k0, k1, t);
+    // the operands of the segment the next k-step lies in (switched once, workgroup-uniform, when the steps reach K)
+    const bf16_t *Ac = A, *Bc = B;
+    long long samc = sam, sbnc = sbn;
+    int kbase = 0, kend = (A_KCONT && B_KCONT && seg2.K > 0) ? min(k1, K) : k1;
+    auto fetch = [&](int kb_) {
+        if (A_KCONT && B_KCONT && seg2.K > 0 && kb_ >= K && kbase == 0) { Ac = seg2.A; Bc = seg2.B; samc = seg2.sam; sbnc = seg2.sbn; kbase = K; kend = k1; }
+        btile_fetch_h<A_KCONT>(ha, Ac, samc, sak, m0, M, kb_ - kbase, kend - kbase, t);
+        btile_fetch_h<B_KCONT>(hb, Bc, sbnc, sbk, n0, N, kb_ - kbase, kend - kbase, t);
+    };
+    fetch(k0);
     for (int kb = k0; kb < k1; kb += BK) {
         btile_store_h<A_KCONT>(As, ha, t);
         btile_store_h<B_KCONT>(Bs, hb, t);
         __syncthreads();
-        btile_fetch_h<A_KCONT>(ha, A, sam, sak, m0, M, kb + BK, k1, t);     // (all zeros past the end)
-        btile_fetch_h<B_KCONT>(hb, B, sbn, sbk, n0, N, kb + BK, k1, t);
+        fetch(kb + BK);         // (all zeros past the end)
         if (!A_KCONT && rowsum && (unsigned)((kb - k0) / BK) % gridDim.x == blockIdx.x && t < TB) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) rs += __builtin_bit_cast(float, (unsigned)As[t][kk] << 16);
@@ -780,7 +790,8 @@ inline Tape* tape_of(pg_handle* h) {
 // leading dimension ldcin; null: C itself, fp32)
 int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const void* A, long long sam, long long sak,
          const void* B, long long sbk, long long sbn, void* C, long long ldc, const float* bias, int flags, int ksplit = 1,
-         const void* mask = nullptr, long long ldm = 0, float* rowsum = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0) {
+         const void* mask = nullptr, long long ldm = 0, float* rowsum = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0,
+         const KSeg2* seg2 = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
     Tape& t = *tape_of(h);
     if ((flags & GEMM_ACC) && !cin) {
@@ -808,7 +819,11 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
         if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
         bool launched = true;
-#define PG_BGEMM(AK, BK_) hipLaunchKernelGGL((bgemm128_kernel<AK, BK_>), g, dim3(256), 0, s, M, N, K, static_cast<const bf16_t*>(A), sam, sak, static_cast<const bf16_t*>(B), sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part, dt, cin, ldcin)
+#define PG_BGEMM(AK, BK_) hipLaunchKernelGGL((bgemm128_kernel<AK, BK_>), g, dim3(256), 0, s, M, N, K, static_cast<const bf16_t*>(A), sam, sak, static_cast<const bf16_t*>(B), sbk, sbn, C, ldc, bias, flags, mask, ldm, rowsum, t.part, t.rs_part, dt, cin, ldcin, sg)
+        const KSeg2 sg = seg2 ? *seg2 : KSeg2{nullptr, nullptr, 0, 0, 0};
+        if (seg2 && !(t.bf16 && abf && bbf && a_kcont && b_kcont && ksplit == 1 && K % BK == 0 && seg2->K % 8 == 0 && seg2->sam % 8 == 0 &&
+                      seg2->sbn % 8 == 0 && reinterpret_cast<uintptr_t>(seg2->A) % 16 == 0 && reinterpret_cast<uintptr_t>(seg2->B) % 16 == 0))
+            return pg_fail(h, PG_EINVAL, "two-segment GEMM: bf16 k-contiguous operands, first segment a multiple of the k-step");
         if (t.bf16) {       // the operand layouts the 16-bit training step uses: forward, dX, dW
             if (!(abf && bbf)) launched = false;
             else if (a_kcont && b_kcont) PG_BGEMM(true, true);
@@ -834,6 +849,7 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
             return PG_OK;
         }
     }
+    if (seg2) return pg_fail(h, PG_EINVAL, "two-segment GEMM outside the 128-tile bf16 kernel");
     // small or unaligned shapes (and operand type mixes the 128-tile kernel has no instantiation for): the 64-tile kernel,
     // then the mask / the row sums as kernels of their own
     if (mask && (ldc != N || ldm != N || ((dt & DT_C) != 0) != ((dt & DT_M) != 0)))
@@ -884,6 +900,13 @@ int linear_fwd(pg_handle* h, hipStream_t s, long long P, int out, int in, const 
         return PG_OK;
     }
     return gemm(h, s, true, true, (int)P, out, in, X, ldx, 1, W, 1, ldw, Y, ldy, b, flags, 1, nullptr, 0, nullptr, dt, cin, ldcin);
+}
+// Y[P,out] = [X1 | X2] [W1 | W2]^T + b (relu): a layer on the concatenation of two inputs in ONE pass (16-bit mode: no fp32
+// partial sum through HBM); in1 a multiple of the k-step
+int linear_fwd2(pg_handle* h, hipStream_t s, long long P, int out, int in1, const void* X1, long long ldx1, const void* W1, long long ldw1,
+                int in2, const void* X2, long long ldx2, const void* W2, long long ldw2, void* Y, long long ldy, const float* b, int flags) {
+    const KSeg2 sg{static_cast<const bf16_t*>(X2), static_cast<const bf16_t*>(W2), ldx2, ldw2, in2};
+    return gemm(h, s, true, true, (int)P, out, in1, X1, ldx1, 1, W1, 1, ldw1, Y, ldy, b, flags, 1, nullptr, 0, nullptr, DT_A | DT_B | DT_C, nullptr, 0, &sg);
 }
 // dX[P,in] (+)= dY[P,out] W[out,in]
 // relu_of: the stored post-activation the consumer of dX was ReLU'd to -- dX is zeroed where it is <= 0 (fused ReLU backward)
@@ -956,11 +979,13 @@ int mlp_forward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, co
     };
     PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, WT(0, 0), CH_X, p.H[0], W, w.w[1], GEMM_RELU, ABC));
     for (int l = 1; l < DEPTH; ++l) {
-        if (l == SKIP + 1) {        // h = cat([x, h]) in front of layer 5 (nerf.py:99-101)
-            void* part = bf ? static_cast<void*>(t.tmpF) : p.H[l];
-            PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, WT(2 * l, 0), CH_X + W, part, W, nullptr, 0, AB));
-            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, CH_X), CH_X + W, p.H[l], W, w.w[2 * l + 1], GEMM_ACC | GEMM_RELU, ABC,
-                              static_cast<const float*>(part), W));
+        if (l == SKIP + 1 && bf) {  // h = cat([x, h]) in front of layer 5 (nerf.py:99-101): the h part's 256 columns first (a whole
+                                    // number of k-steps), then the x part's 432
+            PG_TRY(linear_fwd2(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, CH_X), CH_X + W, CH_X, p.X, XW, WT(2 * l, 0), CH_X + W, p.H[l], W,
+                               w.w[2 * l + 1], GEMM_RELU));
+        } else if (l == SKIP + 1) {
+            PG_TRY(linear_fwd(h, s, P, W, CH_X, p.X, XW, WT(2 * l, 0), CH_X + W, p.H[l], W, nullptr, 0, AB));
+            PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, CH_X), CH_X + W, p.H[l], W, w.w[2 * l + 1], GEMM_ACC | GEMM_RELU, ABC));
         } else {
             PG_TRY(linear_fwd(h, s, P, W, W, p.H[l - 1], W, WT(2 * l, 0), W, p.H[l], W, w.w[2 * l + 1], GEMM_RELU, ABC));
         }
@@ -968,10 +993,12 @@ int mlp_forward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, co
     const void* h7 = p.H[DEPTH - 1];
     PG_TRY(linear_fwd(h, s, P, 1, W, h7, W, w.w[16], W, p.raw + 3, 4, w.w[17], 0, A_));
     PG_TRY(linear_fwd(h, s, P, W, W, h7, W, WT(18, 0), W, p.F, W, w.w[19], 0, ABC));
-    void* gpart = bf ? static_cast<void*>(t.tmpF) : p.G;
-    PG_TRY(linear_fwd(h, s, P, VW, W, p.F, W, WT(20, 0), vcols, gpart, VW, nullptr, 0, AB));
-    PG_TRY(linear_fwd(h, s, P, VW, vk, el_off(p.X, CH_X, es), XW, WT(20, W), vcols, p.G, VW, w.w[21], GEMM_ACC | GEMM_RELU, ABC,
-                      static_cast<const float*>(gpart), VW));
+    if (bf) {
+        PG_TRY(linear_fwd2(h, s, P, VW, W, p.F, W, WT(20, 0), vcols, vk, el_off(p.X, CH_X, es), XW, WT(20, W), vcols, p.G, VW, w.w[21], GEMM_RELU));
+    } else {
+        PG_TRY(linear_fwd(h, s, P, VW, W, p.F, W, WT(20, 0), vcols, p.G, VW, nullptr, 0, AB));
+        PG_TRY(linear_fwd(h, s, P, VW, vk, el_off(p.X, CH_X, es), XW, WT(20, W), vcols, p.G, VW, w.w[21], GEMM_ACC | GEMM_RELU, ABC));
+    }
     PG_TRY(linear_fwd(h, s, P, 3, VW, p.G, VW, w.w[22], VW, p.raw, 4, w.w[23], 0, A_));
     return PG_OK;
 }
@@ -984,12 +1011,9 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
     auto WT = [&](int i, long long off) -> const void* {        // (see mlp_forward)
         return bf ? static_cast<const void*>(t.wb[net][i] + off) : static_cast<const void*>(w.w[i] + off);
     };
-    const size_t sizes[24] = {(size_t)W * CH_X, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * W, W, (size_t)W * (CH_X + W), W,
-                              (size_t)W * W, W, (size_t)W * W, W, W, 1, (size_t)W * W, W, (size_t)VW * vcols, VW, 3 * VW, 3};
-    for (int i = 0; i < 24; ++i) {
+    // (every gradient tensor is written whole below -- the ordered reductions overwrite, nothing accumulates into them)
+    for (int i = 0; i < 24; ++i)
         if (!g.w[i]) return pg_fail(h, PG_EINVAL, "pg_train_backward: gradient tensor %d is null", i);
-        PG_HIP(h, hipMemsetAsync(g.w[i], 0, sizes[i] * sizeof(float), s));
-    }
     const float* d_raw = t.d_raw;
     void* dG = t.dG;
     // rgb_linear: raw[:, :3] = G Wr^T + br
