@@ -201,7 +201,21 @@ struct Stream {
     // in the texture addresser and every wave stalls on the issue.
     uint32_t cur_src, cur_dst;   // stream byte offset / ring byte offset of this wave's share
     uint32_t rd_nxt;             // this lane's ring offset for the chunk AFTER the current one (enter_ahead / issue_ahead)
-    __device__ __forceinline__ void enter_split() {
+    // plain_ok(c): at the entry of stream chunk c the ring bookkeeping is known at compile time -- no masked chunk lies between c
+    // and the chunk behind the one fetched now, and the stream does not wrap there -- so `next_off += CHUNK_BYTES` replaces
+    // advance() (the wrap test, the mask hand-over and skip_masked: ~20 scalar instructions per entry)
+    static constexpr bool plain_ok(int c) {
+        if (c < 0) return false;
+        const int n = c + DEPTH + 1;
+        if (n >= NCHUNK_) return false;
+        if (MASK_NX > 0) {
+            const int xs[3] = {MASK_X0, MASK_X1, MASK_X2};
+            for (int i = 0; i < 3; ++i)
+                if (xs[i] >= 0 && c + 1 <= xs[i] + MASK_NX - 1 && n >= xs[i]) return false;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void enter_split(bool plain = false) {
 #if defined(PG_STAMPS)
         unsigned long long s0, s1, s2;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s0)::"memory");
@@ -218,7 +232,7 @@ struct Stream {
 #endif
         cur_src = next_off + (wave - dma_base()) * (PER * 1024);
         cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);
-        advance();
+        if (plain) next_off += CHUNK_BYTES; else advance();
         fill_slot = fill_slot + 1 == NSLOT ? 0u : fill_slot + 1;
         asm volatile("" : "+s"(next_off), "+s"(fill_slot), "+s"(cur_src), "+s"(cur_dst));
         rd_off = rd_off + CHUNK_BYTES >= (uint32_t)NSLOT * CHUNK_BYTES + lane * 16 ? rd_off - (NSLOT - 1) * CHUNK_BYTES

@@ -118,8 +118,9 @@ __device__ __forceinline__ void lds_retire(a128& r, int younger) {
 
 // A fragment of unit L (compile-time after unrolling) of a segment with T units: NS register
 // sets, reads issued NS-1 units ahead.  ASYNC = false: a plain (compiler-scheduled) read.
+// c0: the segment's first chunk in the stream when the caller knows it (Stream::plain_ok: static ring bookkeeping), else -1
 template <typename V, int T, bool ASYNC, int NS, typename ST>
-__device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
+__device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L, int c0 = -1) {
     constexpr int PER = ST::PER, PSTRIDE = UPC / PER, LA = NS - 1;
     const int q = L % UPC;
     if (!ASYNC) {
@@ -138,7 +139,7 @@ __device__ __forceinline__ V next_a(APipe<V, NS>& p, ST& st, int L) {
     return __builtin_bit_cast(V, p.r[L % NS]);
 #endif
     if (q == 0) {
-        if (PG_SPREAD_DMA) st.enter_split(); else st.enter(L / UPC);
+        if (PG_SPREAD_DMA) st.enter_split(c0 >= 0 && ST::plain_ok(c0 + L / UPC)); else st.enter(L / UPC);
         for (int k = 0; k < LA; ++k)
             if (k <= rem) st.issue(p.r[(L + k) % NS], q + k);
     }

@@ -269,7 +269,7 @@ static_assert(PG_R_BIAS_AT <= HU16 - 3, "the bias fetch needs two more retires o
 // tile pair (VALU, needs the pair's last MFMA to retire) is placed behind the first MFMAs of the next tile, and the
 // next tile's bias is read mid-tile, so that neither sits at a tile boundary where the matrix pipe would drain.
 template <typename V, typename ST>
-__device__ __forceinline__ void hidden_layer16(const V (*fin)[2], V (*fout)[2], ST& st, unsigned bbase, int tile0) {
+__device__ __forceinline__ void hidden_layer16(const V (*fin)[2], V (*fout)[2], ST& st, unsigned bbase, int tile0, int c0) {
     APipe<V> p;
     constexpr int T = HU16 * NT16;
     f32x4 lo0, lo1, hi0, hi1;
@@ -280,7 +280,7 @@ __device__ __forceinline__ void hidden_layer16(const V (*fin)[2], V (*fout)[2], 
         f32x4 acc0, acc1;
 #pragma unroll
         for (int u = 0; u < HU16; ++u) {
-            const V av = next_a<V, T, true, PG_PIPE_H>(p, st, o * HU16 + u);
+            const V av = next_a<V, T, true, PG_PIPE_H>(p, st, o * HU16 + u, c0);
             if (u == 0) acc0 = acc1 = bp.take();
             acc0 = Op16<V>::mfma(av, fin[u][0], acc0);
             acc1 = Op16<V>::mfma(av, fin[u][1], acc1);
@@ -495,6 +495,11 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         };
 
         PG_STAMP(1);
+        // first stream chunk of the segments behind layer 0 (pg_program.h R): where the ring bookkeeping is static (Stream::plain_ok)
+        constexpr int CH = pgp::R::CH_HID;
+        constexpr int C_L1 = pgp::R::CH_L0X + (OC ? pgp::R::NLIMB : 0), C_L5H = C_L1 + 4 * CH, C_L6 = C_L5H + CH + pgp::R::CH_L0X, C_AV = C_L6 + 2 * CH;
+        static_assert(C_L5H + CH == (OC ? pgp::R::C_L5X_OC : pgp::R::C_L5X) && C_AV + pgp::R::CH_AVR == (OC ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK),
+                      "chunk bases follow pg_program.h");
         V fa[HU16][2], fb[HU16][2];
         {   // ---- layer 0: K = 432 generated on the fly, all 16 out tiles live ----
             f32x4 acc[NT16][2];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         }
         PG_STAMP(2);
         // ---- layers 1..4 ----
-        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 1 * NT16);
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 1 * NT16, C_L1);
         if constexpr (OC) {
             // The NEXT pass's (a, b) rows from the staged rays.  The fetch was issued in layer 0's first chunk, possibly
             // between that chunk's refill pieces: the counted wait of the SECOND entry behind it covers it, and that
@@ -537,9 +542,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                        reinterpret_cast<float4*>(smem + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES + k * REC_AB_BYTES + sl * 32));
             }
         }
-        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 2 * NT16);
-        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 3 * NT16);
-        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 4 * NT16);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 2 * NT16, C_L1 + CH);
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 3 * NT16, C_L1 + 2 * CH);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 4 * NT16, C_L1 + 3 * CH);
         PG_STAMP(3);
         {   // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
             f32x4 acc[NT16][2];
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             for (int o = 0; o < NT16; ++o) {
 #pragma unroll
                 for (int u = 0; u < HU16; ++u) {
-                    const V av = next_a<V, HU16 * NT16, true, PG_PIPE_X>(p5, st, o * HU16 + u);
+                    const V av = next_a<V, HU16 * NT16, true, PG_PIPE_X>(p5, st, o * HU16 + u, C_L5H);
                     if (u == 0) acc[o][0] = acc[o][1] = bp.take();
                     acc[o][0] = Op16<V>::mfma(av, fa[u][0], acc[o][0]);
                     acc[o][1] = Op16<V>::mfma(av, fa[u][1], acc[o][1]);
@@ -564,8 +569,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 for (int c = 0; c < 2; ++c) fb[u][c] = relu_pack16<V>(acc[2 * u][c], acc[2 * u + 1][c], true);
         }
         PG_STAMP(4);
-        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 6 * NT16);
-        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 7 * NT16);
+        hidden_layer16<V>(fb, fa, st, bbase, BS_LAYER0 + 6 * NT16, C_L6);
+        hidden_layer16<V>(fa, fb, st, bbase, BS_LAYER0 + 7 * NT16, C_L6 + CH);
         PG_STAMP(5);
         // the NEXT pass's limb mask, from its (a, b) records (in LDS since this pass's second chunk entry): the ring's
         // prefetch pointer wraps to the head of the stream two chunk entries from here and must know it by then
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 f32x4 t0, t1;
 #pragma unroll
                 for (int u = 0; u < HU16; ++u) {
-                    const V av = next_a<V, TAV, true, PG_PIPE_H>(pv, st, o * HU16 + u);
+                    const V av = next_a<V, TAV, true, PG_PIPE_H>(pv, st, o * HU16 + u, C_AV);
                     if (u == 0) t0 = t1 = bp.take();
                     t0 = Op16<V>::mfma(av, fb[u][0], t0);
                     t1 = Op16<V>::mfma(av, fb[u][1], t1);

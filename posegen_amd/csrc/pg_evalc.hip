@@ -217,11 +217,12 @@ constexpr int ABL_PL = 1;
 #else
 constexpr int ABL_PL = 2;
 #endif
+// c0: the segment's first chunk in the stream (compile-time; -1 = unknown / inside a maskable range)
 template <int TP, int NS, typename ST>
-__device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P) {
+__device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P, int c0 = -1) {
     constexpr int LA = NS - 1;
     if (P % PPC != 0) return;
-    st.enter_split();
+    st.enter_split(c0 >= 0 && ST::plain_ok(c0 + P / PPC));
     const int rem = min(TP - 1 - P, PPC - 1);            // later pairs of this segment in this chunk
 #pragma clang loop unroll(full)
     for (int k = 0; k < LA; ++k)
@@ -254,7 +255,7 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
 // read, (ReLU'd,) and split: 8 half steps (A and B of 4 value pairs) spread over the NO out tiles.
 // T = units (of 1 KiB) of the segment in the weight stream: 2 per (input unit, out tile).
 template <int NO, int NU, bool RELU, typename ST, typename SRC>
-__device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, float s129) {
+__device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, float s129, int c0 = -1) {
     constexpr int TP = NU * NO;
     constexpr int PER = (8 + NO - 1) / NO;            // half steps per out tile
     PairPipe<NSC> p;
@@ -274,10 +275,10 @@ __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, f
             // moves the second plane's MFMA of tile o above the first of tile o + 1 in places -- pinning the order: no change)
             if (NO % 2 == 0) {
                 if ((o & 1) == 0) {
-                    pair_begin<TP>(p, st, P);
+                    pair_begin<TP>(p, st, P, c0);
                     acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(cur.x1), acc[o], 0, 0, 0);
                     pair_mid<TP>(p, st, P);
-                    pair_begin<TP>(p, st, P + 1);
+                    pair_begin<TP>(p, st, P + 1, c0);
                     acc[o + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[(P + 1) % NSC][0]), frag_v(cur.x1), acc[o + 1], 0, 0, 0);
                     acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
                 } else {
@@ -285,7 +286,7 @@ __device__ __forceinline__ void segment_c(f32x16* acc, ST& st, const SRC& src, f
                     acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
                 }
             } else {
-                pair_begin<TP>(p, st, P);
+                pair_begin<TP>(p, st, P, c0);
                 acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][0]), frag_v(cur.x1), acc[o], 0, 0, 0);
                 pair_mid<TP>(p, st, P);
                 acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(VC, p.r[P % NSC][PG_PL1]), frag_v(cur.x2), acc[o], 0, 0, 0);
@@ -798,6 +799,12 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         static_assert(MAXR_CR * 11 <= 64 && 2 * MAXR_CR <= 64, "the staged rays fit one dword DMA each");
 
         PG_STAMP(1);
+        // first stream chunk of the segments behind layer 0 (pg_program.h C): where the ring bookkeeping is static (Stream::plain_ok)
+        constexpr int CH = pgp::C::CH_HID;
+        constexpr int C_L1 = REC ? pgp::C::CH_L0XR + (OC ? pgp::C::NPAIRJ : 0) : pgp::C::CH_L0X;
+        constexpr int C_L5H = C_L1 + 4 * CH, C_L6 = C_L5H + CH + (REC ? pgp::C::CH_L0XR : pgp::C::CH_L0X), C_AV = C_L6 + 2 * CH;
+        static_assert(!OC || C_L5H + CH == pgp::C::C_L5XR_OC, "chunk bases follow pg_program.h");
+        static_assert(!REC || OC || C_L5H + CH == pgp::C::C_L5XR, "chunk bases follow pg_program.h");
         f32x16 accA[NT], accB[NT];
         // ---- layer 0: K = 432 generated on the fly ----
 #pragma unroll
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         auto srcB = [&](int u, int e) { return accB[u >> 1][8 * (u & 1) + e]; };
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 1 * NT + o, h);
-        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        segment_c<NT, HU, true>(accB, st, srcA, s129, C_L1);
         if constexpr (OC) {
             // The NEXT pass's (a, b) rows from the staged rays.  The fetch was issued in layer 0's first chunk, possibly
             // between that chunk's refill pieces: the counted wait of the SECOND entry behind it covers it, and that
@@ -842,18 +849,18 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         }
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 2 * NT + o, h);
-        segment_c<NT, HU, true>(accA, st, srcB, s129);
+        segment_c<NT, HU, true>(accA, st, srcB, s129, C_L1 + CH);
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 3 * NT + o, h);
-        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        segment_c<NT, HU, true>(accB, st, srcA, s129, C_L1 + 2 * CH);
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 4 * NT + o, h);
-        segment_c<NT, HU, true>(accA, st, srcB, s129);
+        segment_c<NT, HU, true>(accA, st, srcB, s129, C_L1 + 3 * CH);
         PG_STAMP(3);
         // ---- layer 5: [x(432), h4(256)] -> 256 (skip connection, nerf.py:99-101) ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 5 * NT + o, h);
-        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        segment_c<NT, HU, true>(accB, st, srcA, s129, C_L5H);
         PG_STAMP(4);
         if constexpr (REC) x_segment_cr(accB, st, ab, zz, cutv, tlv, s129, wmask, gmask, NoHook());
         else x_segment_c(accB, st, ab, zz, cutv, tlv, s129);
@@ -861,10 +868,10 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         // ---- layers 6, 7 ----
 #pragma unroll
         for (int o = 0; o < NT; ++o) accA[o] = load_bias(bias, BT_LAYER0 + 6 * NT + o, h);
-        segment_c<NT, HU, true>(accA, st, srcB, s129);
+        segment_c<NT, HU, true>(accA, st, srcB, s129, C_L6);
 #pragma unroll
         for (int o = 0; o < NT; ++o) accB[o] = load_bias(bias, BT_LAYER0 + 7 * NT + o, h);
-        segment_c<NT, HU, true>(accB, st, srcA, s129);
+        segment_c<NT, HU, true>(accB, st, srcA, s129, C_L6 + CH);
         if (TAPS && a.dbg && a.dbg_stage == 7 && valid) {
 #pragma unroll
             for (int i = 0; i < HSEQ; ++i) a.dbg[gp * W + hseq_channel(i, h)] = fmaxf(accB[i >> 4][i & 15], 0.0f);
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(NTHR_C, 1) void evalc_kernel(const EvalArgs a) {
         av[0] = load_bias(bias, TB_ALPHA, h);
 #pragma unroll
         for (int o = 0; o < NTV; ++o) av[1 + o] = load_bias(bias, TB_VIEWF + o, h);
-        segment_c<NTV + 1, HU, true>(av, st, srcB, s129);
+        segment_c<NTV + 1, HU, true>(av, st, srcB, s129, C_AV);
         const float sigma = av[0][0];
         PG_STAMP(7);
         // ---- view directions: per-ray sin/cos table in LDS times the per-point cutoff weight ----
