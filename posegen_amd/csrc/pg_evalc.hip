@@ -53,9 +53,9 @@ using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C, pgp::C::NPAIRJ, 0, p
 // on-chip variant (no per-ray records in HBM): the joint-pair chunks of the view layer's direction weights sit behind layer 0
 using StreamCRO = Stream<NWAVE_C, pgp::C::NCHUNK_OC, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR_OC, pgp::C::C_YC>;
 #ifndef PG_NSC
-#define PG_NSC 4
+#define PG_NSC 5
 #endif
-constexpr int NSC = PG_NSC;                   // register sets of the A pipe: reads issued NSC-1 PAIRS of units ahead
+constexpr int NSC = PG_NSC;                   // register sets of the A pipe: reads issued NSC-1 PAIRS of units ahead (two pairs retire per wait)
 constexpr int LDS_TOTAL_C = LDS_RTAB + MAXR_C * SLOTC_FLOATS * 4;
 static_assert(LDS_TOTAL_C <= 160 * 1024, "LDS budget of one CU");
 // LDS carve-up of the record variant (bytes): the ring, a compacted bias table (pg_layout.h BTC_*), the cutoff
@@ -176,6 +176,7 @@ __device__ __forceinline__ void piece_c(PairPipe<NS>& p, const ST& st, int i) {
         PG_PC(0) PG_PC(1) PG_PC(2) PG_PC(3)
 #undef PG_PC
     }
+
 }
 
 #if PG_RING_SLOTS >= 4
@@ -245,7 +246,15 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
     if (P == TP - 1)            // a segment ending inside the chunk flushes the rest of the refill
         for (int i = (q + 1) >> 1; i < ST::PER; ++i) piece_c(p, st, i);
 #endif
-    if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], ABL_PL * min(LA - 1, rem - 1));
+    // one counted wait per TWO pairs, behind the even pairs of a chunk (pairs P + 1 and P + 2 retire together; the pipe is one
+    // pair deeper for it): four instructions less per input unit of the SIMD's only wave (-0.4 ... -0.7 %)
+    if ((q & 1) == 0) {
+        if (rem >= 2) {
+            const int outstanding = ABL_PL * max(min(LA, rem) - 2, 0);
+            retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], outstanding);
+            asm volatile("" : "+v"(p.r[(P + 2) % NS][0]), "+v"(p.r[(P + 2) % NS][1]));
+        } else if (rem >= 1) retire_pair(p.r[(P + 1) % NS][0], p.r[(P + 1) % NS][1], ABL_PL * min(LA - 1, rem - 1));
+    }
 }
 
 #endif
