@@ -225,6 +225,10 @@ __device__ __forceinline__ void pair_begin(PairPipe<NS>& p, ST& st, int P, int c
     if (P % PPC != 0) return;
     st.enter_split(c0 >= 0 && ST::plain_ok(c0 + P / PPC));
     const int rem = min(TP - 1 - P, PPC - 1);            // later pairs of this segment in this chunk
+#if defined(PG_ABL_NOREAD)      // timing ablation only (wrong results): no ring reads, no waits for them
+    asm volatile("" : "+v"(p.r[P % NS][0]), "+v"(p.r[P % NS][1]));
+    if (true) return;
+#endif
 #pragma clang loop unroll(full)
     for (int k = 0; k < LA; ++k)
         if (k <= rem) { st.issue(p.r[(P + k) % NS][0], 2 * k); if (ABL_PL == 2) st.issue(p.r[(P + k) % NS][1], 2 * k + 1); }
@@ -236,7 +240,9 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
     constexpr int LA = NS - 1;
     const int q = P % PPC;
     const int rem = min(TP - 1 - P, PPC - 1 - q);
+#if !defined(PG_ABL_NOREAD)
     if (LA <= rem) { st.issue(p.r[(P + LA) % NS][0], 2 * (q + LA)); if (ABL_PL == 2) st.issue(p.r[(P + LA) % NS][1], 2 * (q + LA) + 1); }
+#endif
 #if defined(PG_ABL_SINGLE)
     if ((q & 3) == 3) piece_c(p, st, q >> 2);
     if (P == TP - 1)
@@ -248,6 +254,10 @@ __device__ __forceinline__ void pair_mid(PairPipe<NS>& p, ST& st, int P) {
 #endif
     // one counted wait per TWO pairs, behind the even pairs of a chunk (pairs P + 1 and P + 2 retire together; the pipe is one
     // pair deeper for it): four instructions less per input unit of the SIMD's only wave (-0.4 ... -0.7 %)
+#if defined(PG_ABL_NOREAD)
+    asm volatile("" : "+v"(p.r[(P + 1) % NS][0]), "+v"(p.r[(P + 1) % NS][1]));
+    if (true) return;
+#endif
     if ((q & 1) == 0) {
         if (rem >= 2) {
             const int outstanding = ABL_PL * max(min(LA, rem) - 2, 0);
