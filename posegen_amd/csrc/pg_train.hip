@@ -641,6 +641,16 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
 
+// ... and the transposed bf16 copy of the rows x cols block of a weight matrix (leading dimension ld) the dX GEMMs read: dst[c][r]
+__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, long long ld, int rows, int cols, bf16_t* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < rows && c0 + tx < cols) ? src[(long long)(r0 + i) * ld + c0 + tx] : 0.0f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(long long)(c0 + i) * rows + r0 + tx] = f2bf(tile[tx][i]);
+}
+
 // part[block][n] = sum over the block's 256 rows of d[row * ld + n] (bias gradients; reduce_parts_kernel adds the
 // blocks in order)
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part, int bf) {
@@ -760,6 +770,7 @@ struct Tape {
     float *rays = nullptr, *cams = nullptr;
     void *tmpA = nullptr, *tmpB = nullptr, *dG = nullptr;       // activation gradients (tape element type)
     bf16_t* wb[2][24] = {};                                     // 16-bit mode: bf16 copies of the weight matrices (even tensor indices)
+    bf16_t* wbT[2][24] = {};                                    // ... and transposed copies [in][out] of the blocks the dX GEMMs multiply by
     float *tmpF = nullptr;                                      // 16-bit mode: fp32 partial sums of the two-part layers (skip layer, view layer, dH7)
     float *dC = nullptr, *d_raw = nullptr;
     float *part = nullptr, *rs_part = nullptr, *ray_g = nullptr;      // split-K slices, row / column sum shares, per-ray code gradients
@@ -912,7 +923,10 @@ int linear_fwd2(pg_handle* h, hipStream_t s, long long P, int out, int in1, cons
 // relu_of: the stored post-activation the consumer of dX was ReLU'd to -- dX is zeroed where it is <= 0 (fused ReLU backward)
 // dt: DT_A = dY, DT_C = dX, DT_M = relu_of are bf16
 int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* dY, long long ldy, const void* W, long long ldw,
-                 void* dX, long long ldx, int flags, const void* relu_of = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0) {
+                 void* dX, long long ldx, int flags, const void* relu_of = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0,
+                 const bf16_t* WT = nullptr) {
+    // WT: the step's transposed bf16 copy [in][out] of W's block -- both operands k-contiguous (16-byte tile stores, no transposing ones)
+    if (WT) return gemm(h, s, true, true, (int)P, in, out, dY, ldy, 1, WT, 1, out, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
     return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
 }
 // dW[out,in] = dY[P,out]^T X[P,in] (split-K over the points, slices summed in order); dt: DT_A = dY, DT_B = X are bf16
@@ -1025,7 +1039,7 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
     PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols, g.w[21], AB));
     PG_TRY(linear_bwd_w(h, s, P, VW, vk, dG, VW, el_off(p.X, CH_X, es), XW, g.w[20] + W, vcols, nullptr, AB));
     void* dF = t.tmpA;
-    PG_TRY(linear_bwd_x(h, s, P, VW, W, dG, VW, WT(20, 0), vcols, dF, W, 0, nullptr, ABC));
+    PG_TRY(linear_bwd_x(h, s, P, VW, W, dG, VW, WT(20, 0), vcols, dF, W, 0, nullptr, ABC, nullptr, 0, bf ? t.wbT[net][20] : nullptr));
     if (fc && g.codes) {
         PG_HIP(h, hipMemsetAsync(g.codes, 0, (size_t)w.n_codes * FC_CH * sizeof(float), s));
         PG_TRY(linear_bwd_x(h, s, P, VW, FC_CH, dG, VW, w.w[20] + W + CH_D, vcols, t.dC, FC_CH, 0, nullptr, A_));
@@ -1040,7 +1054,7 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
     void* dH = t.tmpB;              // dH7 = (alpha's part + feature's part) * [H7 > 0]: the mask rides on the second GEMM
     void* dpart = bf ? static_cast<void*>(t.tmpF) : dH;      // (16-bit mode: alpha's part in fp32, rounded once with the sum)
     PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dpart, W, 0));
-    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, GEMM_ACC, h7, ABCM, static_cast<const float*>(dpart), W));
+    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, GEMM_ACC, h7, ABCM, static_cast<const float*>(dpart), W, bf ? t.wbT[net][18] : nullptr));
     PG_TRY(linear_bwd_w(h, s, P, 1, W, d_raw + 3, 4, h7, W, g.w[16], W, nullptr, B_));
     PG_TRY(colsum(h, s, d_raw + 3, P, 1, 4, g.w[17]));
     // the trunk, back to front: dZ_l = dH_l * [H_l > 0]
@@ -1052,11 +1066,11 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
         } else if (l == SKIP + 1) {
             PG_TRY(linear_bwd_w(h, s, P, W, CH_X, dH, W, p.X, XW, g.w[2 * l], CH_X + W, g.w[2 * l + 1], AB));
             PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l] + CH_X, CH_X + W, nullptr, AB));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, CH_X), CH_X + W, other, W, 0, p.H[l - 1], ABCM));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, CH_X), CH_X + W, other, W, 0, p.H[l - 1], ABCM, nullptr, 0, bf ? t.wbT[net][2 * l] : nullptr));
             std::swap(dH, other);
         } else {
             PG_TRY(linear_bwd_w(h, s, P, W, W, dH, W, p.H[l - 1], W, g.w[2 * l], W, g.w[2 * l + 1], AB));
-            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, 0), W, other, W, 0, p.H[l - 1], ABCM));
+            PG_TRY(linear_bwd_x(h, s, P, W, W, dH, W, WT(2 * l, 0), W, other, W, 0, p.H[l - 1], ABCM, nullptr, 0, bf ? t.wbT[net][2 * l] : nullptr));
             std::swap(dH, other);
         }
     }
@@ -1115,7 +1129,11 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     const int vcols_ = W + CH_D + (fc ? FC_CH : 0);
     const size_t wsize[24] = {(size_t)W * CH_X, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * W, 0, (size_t)W * (CH_X + W), 0,
                               (size_t)W * W, 0, (size_t)W * W, 0, 0, 0, (size_t)W * W, 0, (size_t)VW * vcols_, 0, 0, 0};     // the large GEMMs' weight matrices
-    if (bf) for (int i = 0; i < 24; ++i) need += 2 * al(wsize[i] * 2);
+    // blocks of the weight matrices the dX GEMMs multiply by: (rows = out, cols = in, first column); layer 0 has no dX
+    struct TB_ { int rows, cols, col0; };
+    const TB_ tblock[24] = {{0, 0, 0}, {}, {W, W, 0}, {}, {W, W, 0}, {}, {W, W, 0}, {}, {W, W, 0}, {}, {W, W, CH_X}, {}, {W, W, 0}, {}, {W, W, 0}, {}, {}, {},
+                            {W, W, 0}, {}, {VW, W, 0}, {}, {}, {}};
+    if (bf) for (int i = 0; i < 24; ++i) need += 2 * al(wsize[i] * 2) + 2 * al((size_t)tblock[i].rows * tblock[i].cols * 2);
     if (need > t.bytes) {
         if (t.buf) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(t.buf)); t.buf = nullptr; t.bytes = 0; }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.buf), need);
@@ -1149,12 +1167,20 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     t.dG = take((size_t)Pm * VW * es); t.dC = take((size_t)Pm * FC_CH * 4); t.d_raw = take((size_t)Pm * 16);
     t.tmpF = bf ? take((size_t)Pm * W * 4) : nullptr;
     for (int k = 0; k < 2; ++k)
-        for (int i = 0; i < 24; ++i) t.wb[k][i] = (bf && wsize[i]) ? reinterpret_cast<bf16_t*>(take(wsize[i] * 2)) : nullptr;
+        for (int i = 0; i < 24; ++i) {
+            t.wb[k][i] = (bf && wsize[i]) ? reinterpret_cast<bf16_t*>(take(wsize[i] * 2)) : nullptr;
+            t.wbT[k][i] = (bf && tblock[i].rows) ? reinterpret_cast<bf16_t*>(take((size_t)tblock[i].rows * tblock[i].cols * 2)) : nullptr;
+        }
     if (bf) {       // this step's bf16 copies of the weight matrices (the parameters do not change between forward and backward)
         for (int k = 0; k < (N > 0 ? 2 : 1); ++k)
             for (int i = 0; i < 24; ++i) {
                 if (!wsize[i]) continue;
                 hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)((wsize[i] + 1023) / 1024)), dim3(256), 0, s, (k ? fine : coarse)->w[i], t.wb[k][i], (long long)wsize[i]);
+                if (tblock[i].rows) {
+                    const long long ldw = (long long)(wsize[i] / tblock[i].rows);       // (= the matrix's column count)
+                    hipLaunchKernelGGL(cvt_bf16_t_kernel, dim3((tblock[i].cols + 31) / 32, (tblock[i].rows + 31) / 32), dim3(256), 0, s,
+                                       (k ? fine : coarse)->w[i] + tblock[i].col0, ldw, tblock[i].rows, tblock[i].cols, t.wbT[k][i]);
+                }
             }
         PG_LAUNCH_CHECK(h, "weight conversion");
     }
