@@ -16,3 +16,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
 find $out -name "*.csv" | head -40
 cd /tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $out/lds -- $B > $out/lds.log 2>&1
+# issue / wait / scalar / instruction-fetch counters (profiles/r4_*_pmc_extra.csv): three more passes, EXTRA=1 to collect
+if [ -n "$EXTRA" ]; then
+  timeout -k 10 300 rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU --kernel-trace --output-format csv -d $out/x1 -- $B > $out/x1.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL --kernel-trace --output-format csv -d $out/x2 -- $B > $out/x2.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_LDS_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $out/x3 -- $B > $out/x3.log 2>&1
+fi
