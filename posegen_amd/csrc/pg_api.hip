@@ -117,7 +117,8 @@ pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     t.view_w = ns.host[20].data();  t.view_b = ns.host[21].data();
     t.view_cols = W + CH_D + cfg.framecode_ch;
     t.rgb_w = ns.host[22].data();   t.rgb_b = ns.host[23].data();
-    t.fold();
+    if (ns.fold_w.empty()) { t.fold(); ns.fold_w = t.viewf_w; ns.fold_b = t.viewf_b; }      // (every packer of the net shares it)
+    else { t.viewf_w = ns.fold_w; t.viewf_b = ns.fold_b; }
     return t;
 }
 
@@ -588,6 +589,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     }
     NetState& ns = h->net[which];
     ns.host.assign(24, {});
+    ns.fold_w.clear(); ns.fold_b.clear();
     for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + want[i][0] * want[i][1]);
     ns.loaded = true;
     PG_HIP(h, hipSetDevice(h->device));

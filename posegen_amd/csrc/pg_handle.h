@@ -13,6 +13,7 @@ struct NetState {
     bool loaded = false;
     std::vector<std::vector<float>> host;      // 24 tensors, reference order (see header)
     std::vector<float> codes_host;             // [n_codes+1,16]
+    mutable std::vector<float> fold_w, fold_b; // W_view[:, :256] W_feature and its bias (NetTensors::fold), formed once per pg_load_weights
     int n_codes = 0;
     uint8_t* d_stream[PG_PREC_COUNT][2] = {};     // [precision][factorised view layer]
     uint8_t* d_vy[PG_PREC_COUNT] = {};            // Y-stage weights of the per-ray record kernel (pg_rayrec.hip)

@@ -88,11 +88,15 @@ void NetTensors::fold() {
         double bsum = view_b ? view_b[o] : 0.0;
         for (int m = 0; m < W; ++m) bsum += (double)vr[m] * (feat_b ? feat_b[m] : 0.f);
         viewf_b[o] = (float)bsum;
-        for (int k = 0; k < W; ++k) {
-            double acc = 0.0;
-            for (int m = 0; m < W; ++m) acc += (double)vr[m] * feat_w[(size_t)m * W + k];
-            viewf_w[(size_t)o * W + k] = (float)acc;
+        // (row o of W_view[:, :256] W_feature: the sums run over m in the same order as before, k innermost for contiguous reads)
+        double acc[W];
+        for (int k = 0; k < W; ++k) acc[k] = 0.0;
+        for (int m = 0; m < W; ++m) {
+            const double v = vr[m];
+            const float* fr = feat_w + (size_t)m * W;
+            for (int k = 0; k < W; ++k) acc[k] += v * fr[k];
         }
+        for (int k = 0; k < W; ++k) viewf_w[(size_t)o * W + k] = (float)acc[k];
     }
 }
 
