@@ -266,19 +266,14 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     return PG_OK;
 }
 
-// the packed weight streams a precision mode will use for net `which`, built ahead of the first render
+// the packed weight stream a precision mode will use for net `which` in the usual call (rays with >= 64 samples; one pose
+// per call unless the config has frame codes), built ahead of the first render; the other forms of the mode (per-ray poses,
+// short rays, explicit points) are packed by the first call that needs them (launch_eval_one)
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
     auto one = [&](int prec) {
-        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) {       // + the direct kernel's stream (short rays, points)
-            int rc = ensure_stream_r(h, which, prec);
-            if (!rc && h->cfg.framecode_ch == 0) rc = ensure_stream_ro(h, which, prec);
-            return rc ? rc : ensure_stream(h, which, prec, false);
-        }
-        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) {     // + the direct form's stream (32 <= S < 64)
-            int rc = ensure_stream_cr(h, which);
-            if (!rc && h->cfg.framecode_ch == 0) rc = ensure_stream_co(h, which);
-            if (rc) return rc;
-        }
+        const bool fc = h->cfg.framecode_ch > 0;
+        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
+        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
     };
     if (mode != PG_PREC_FP16M) return one(mode);
