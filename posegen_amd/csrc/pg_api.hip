@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 #include <mutex>
@@ -583,6 +584,8 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
                         (long long)shapes[2 * i], (long long)shapes[2 * i + 1], (long long)want[i][0], (long long)want[i][1]);
     }
     NetState& ns = h->net[which];
+    static const bool time_load = std::getenv("POSEGEN_TIME_LOAD") != nullptr;
+    const auto tl0 = std::chrono::steady_clock::now();
     ns.host.assign(24, {});
     ns.fold_w.clear(); ns.fold_b.clear();
     for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + want[i][0] * want[i][1]);
@@ -604,8 +607,14 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
     if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    const auto tl1 = std::chrono::steady_clock::now();
     const int rc0 = ensure_mode_streams(h, which, h->cfg.precision);
     if (rc0) return rc0;
+    if (time_load) {
+        const auto tl2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pg_load_weights net %d: copy + free + fold + bias %.2f ms, stream of the mode %.2f ms\n", which,
+                     std::chrono::duration<double, std::milli>(tl1 - tl0).count(), std::chrono::duration<double, std::milli>(tl2 - tl1).count());
+    }
     PG_FORWARD(h, pg_load_weights(hh, which, tensors, shapes, n_tensors));
     return PG_OK;
 }
