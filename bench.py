@@ -527,6 +527,9 @@ def main():
     result["roofline"]["executed_flop_per_point"] = ex
     result["roofline"]["executed_tflops"] = k_tflops * ex / flops_pt
     result["roofline"]["executed_frac"] = k_tflops * ex / flops_pt / peak
+    result["roofline"]["executed_note"] = ("executed_* = the kernel's PROGRAM (every limb / joint pair in range): an upper bound since round 4 -- the "
+                                           "MFMAs a launch really issues (limbs out of cutoff range are skipped) are in the committed PMC pass, "
+                                           "SQ_INSTS_MFMA of profiles/r4_*_pmc.csv")
 
     # What this box SUSTAINS on bare 32x32x16 MFMAs (register operands, 2 waves per SIMD on every CU,
     # nothing else in the loop, one >= 20 ms launch): `peak` stays the nominal dense figure, this says how
