@@ -57,6 +57,11 @@ template <> struct Op16<f16x8> {
 using StreamR = Stream<NWAVE, pgp::R::NCHUNK, PG_DMA_WAVES, pgp::R::NLIMB, 0, pgp::R::C_L5X>;
 // on-chip variant (no per-ray records in HBM): the limb chunks of the view layer's direction weights sit behind layer 0
 using StreamRO = Stream<NWAVE, pgp::R::NCHUNK_OC, PG_DMA_WAVES, pgp::R::NLIMB, 0, pgp::R::C_L5X_OC, pgp::R::C_Y>;
+// where the ring bookkeeping of a chunk entry is static (Stream::plain_ok): not where a maskable chunk or the wrap is within reach
+static_assert(StreamRO::plain_ok(14) && StreamRO::plain_ok(30) && !StreamRO::plain_ok(31) && StreamRO::plain_ok(42) && StreamRO::plain_ok(49) &&
+              !StreamRO::plain_ok(50) && StreamRO::plain_ok(13) && !StreamRO::plain_ok(5) && !StreamRO::plain_ok(2), "on-chip stream");
+static_assert(StreamR::plain_ok(8) && StreamR::plain_ok(24) && !StreamR::plain_ok(25) && StreamR::plain_ok(36) && StreamR::plain_ok(43) && !StreamR::plain_ok(44),
+              "record stream");
 
 // LDS carve-up of this kernel (bytes)
 constexpr int LDSR_RING = 0;

@@ -52,6 +52,11 @@ using StreamC = Stream<NWAVE_C, pgp::C::NCHUNK, NWAVE_C>;
 using StreamCR = Stream<NWAVE_C, pgp::C::NCHUNK_R, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR>;
 // on-chip variant (no per-ray records in HBM): the joint-pair chunks of the view layer's direction weights sit behind layer 0
 using StreamCRO = Stream<NWAVE_C, pgp::C::NCHUNK_OC, NWAVE_C, pgp::C::NPAIRJ, 0, pgp::C::C_L5XR_OC, pgp::C::C_YC>;
+// where the ring bookkeeping of a chunk entry is static (Stream::plain_ok): not where a maskable chunk or the wrap is within reach
+static_assert(StreamCRO::plain_ok(27) && StreamCRO::plain_ok(63) && !StreamCRO::plain_ok(64) && !StreamCRO::plain_ok(70) && StreamCRO::plain_ok(82) &&
+              StreamCRO::plain_ok(100) && !StreamCRO::plain_ok(101) && !StreamCRO::plain_ok(12) && !StreamCRO::plain_ok(5) && StreamCRO::plain_ok(26), "on-chip stream: L1 .. L5h, L6 .. rgb");
+static_assert(StreamCR::plain_ok(15) && StreamCR::plain_ok(51) && !StreamCR::plain_ok(52) && StreamCR::plain_ok(70) && StreamCR::plain_ok(88) &&
+              !StreamCR::plain_ok(89), "record stream");
 #ifndef PG_NSC
 #define PG_NSC 5
 #endif
