@@ -30,6 +30,8 @@ int pg_eval32_points_per_pass(void);
 int pg_launch_evalc(const pgd::EvalArgs* a, int framecode, int rec, int grid, void* stream);
 int pg_launch_ray_records_c(const pgd::RecArgs* a, int framecode, int n_cu, void* stream);
 int pg_evalc_points_per_pass(void);
+int pg_launch_evalc2(const pgd::EvalArgs* a, int framecode, int grid, void* stream);
+int pg_evalc2_points_per_pass(void);
 int pg_launch_sample_coarse(const float* rays, const float* cyls, long long cyl_stride, long long n, int chunk,
                             int S, int lindisp, float* near_far, float* z, const float* t_rand, double* scratch, void* stream);
 long long pg_sample_coarse_scratch(long long n, int chunk);
@@ -253,6 +255,37 @@ int ensure_stream_co(pg_handle* h, int which) {
     return PG_OK;
 }
 
+// PG_PREC_FP16C with >= pgp::T::MIN_S samples per ray runs in the kernel that splits the OUT TILES over the waves
+// (pg_evalc2.hip: two waves per SIMD, activations in LDS, weights straight from L2) -- whatever the pose stride, with or
+// without frame codes; POSEGEN_EVALC2=0 keeps the calls on pg_evalc.hip (A/B, and the record / on-chip forms' tests)
+bool use_evalc2(int S) {
+    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_EVALC2"); return !(e && e[0] == '0'); }();
+    return allowed && S >= pgp::T::MIN_S;
+}
+
+// its weights (pg_program.h T) and the 16-row bias table it shares with the 16x16x32 kernel
+int ensure_c2(pg_handle* h, int which) {
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
+    if (ns.d_c2 && ns.d_bias_s) return PG_OK;
+    const pgpack::NetTensors t = tensors_of(ns, h->cfg);
+    PG_HIP(h, hipSetDevice(h->device));
+    if (!ns.d_c2) {
+        std::vector<uint8_t> packed;
+        const int rc = pgpack::pack_c2(t, h->cfg.framecode_ch > 0, packed);
+        if (rc != 0) return pg_fail(h, PG_EINVAL, "compensated-fp16 tile-split weight packing failed (%d)", rc);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_c2), packed.size()));
+        PG_HIP(h, hipMemcpy(ns.d_c2, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    }
+    if (!ns.d_bias_s) {
+        std::vector<float> b;
+        pgpack::pack_bias_s(t, b);
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias_s), b.size() * sizeof(float)));
+        PG_HIP(h, hipMemcpy(ns.d_bias_s, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return PG_OK;
+}
+
 int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -274,6 +307,7 @@ int ensure_mode_streams(pg_handle* h, int which, int mode) {
     auto one = [&](int prec) {
         const bool fc = h->cfg.framecode_ch > 0;
         if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
+        if (prec == PG_PREC_FP16C && use_evalc2(FACT_MIN_S)) return ensure_c2(h, which);
         if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
     };
@@ -315,9 +349,10 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fc = h->cfg.framecode_ch > 0;
     const bool onchip = sa && fact && !dbg && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
-    const bool conchip = compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
-    const bool crec = compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
-    int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec)
+    const bool c2 = compk && (!dbg || dbg_stage == 99) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
+    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
+    const bool crec = !c2 && compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
+    int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec) : c2 ? ensure_c2(h, which)
            : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
     const int y_bytes = crec ? RECC_Y_BYTES : REC_Y_BYTES;
@@ -327,10 +362,10 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     pgd::EvalArgs a{};
     a.rays = rays; a.z = z; a.pts = points; a.pnoise = pnoise; a.skts = skts; a.cams = cams;
     a.codes = fc ? ns.d_codes : nullptr;
-    a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : conchip ? ns.d_stream_co : crec ? ns.d_stream_cr
+    a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : c2 ? ns.d_c2 : conchip ? ns.d_stream_co : crec ? ns.d_stream_cr
               : ns.d_stream[prec][fact];
     a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : nullptr;
-    a.bias = (recs || onchip) ? ns.d_bias_s : ns.d_bias;
+    a.bias = (recs || onchip || c2) ? ns.d_bias_s : ns.d_bias;
     if (recs || crec) {
         a.rec_y = h->rec;
         a.rec_ab = reinterpret_cast<const float*>(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes);
@@ -355,7 +390,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     a.tau_d = h->tau[1];
     a.dbg_stage = dbg_stage;
     a.far_skip = h->far_skip ? 1 : 0;
-    const int pts = sa ? pg_eval16_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
+    const int pts = sa ? pg_eval16_points_per_pass() : c2 ? pg_evalc2_points_per_pass() : compk ? pg_evalc_points_per_pass() : pg_eval32_points_per_pass();
     if (!points && S < pts / (MAXR - 1))      // explicit points are one pseudo ray: a pass touches one slot
         return pg_fail(h, PG_EINVAL, "N_samples=%d too small: the fused kernel needs >= %d samples per ray", S, pts / (MAXR - 1));
     const long long iters = (a.n_points + pts - 1) / pts;
@@ -394,6 +429,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     }
     int e = (recs || onchip) ? pg_launch_eval16r(&a, prec == PG_PREC_FP16, fc, onchip, grid, stream)
           : sa ? pg_launch_eval16(&a, prec == PG_PREC_FP16, fc, grid, stream)
+          : c2 ? pg_launch_evalc2(&a, fc, grid, stream)
           : compk ? pg_launch_evalc(&a, fc, conchip ? 2 : crec ? 1 : 0, grid, stream)
                : pg_launch_eval32(&a, prec, fc, grid, stream);
     if (h->profiling) {
@@ -552,6 +588,7 @@ void pg_destroy(pg_handle* h) {
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
         if (ns.d_stream_cr) (void)hipFree(ns.d_stream_cr);
         if (ns.d_stream_co) (void)hipFree(ns.d_stream_co);
+        if (ns.d_c2) (void)hipFree(ns.d_c2);
         if (ns.d_vyc) (void)hipFree(ns.d_vyc);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
@@ -602,6 +639,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
     if (ns.d_stream_cr) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_cr)); ns.d_stream_cr = nullptr; }
     if (ns.d_stream_co) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_co)); ns.d_stream_co = nullptr; }
+    if (ns.d_c2) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_c2)); ns.d_c2 = nullptr; }
     if (ns.d_vyc) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_vyc)); ns.d_vyc = nullptr; }
     std::vector<float> bias;
     pgpack::pack_bias(tensors_of(ns, h->cfg), bias);

@@ -326,6 +326,79 @@ int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out,
     return out.size() == (size_t)(onchip ? R::NCHUNK_OC : R::NCHUNK) * CHUNK_BYTES ? 0 : -2;
 }
 
+// ---- compensated kernel with the out tiles split over the waves (pg_evalc2.hip, pg_program.h T): no stream, one
+// 4-KiB block of four A fragments per (k-unit, wave): [tile t of the wave][plane], lane (g, row): k = 8 g + e ----
+int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out) {
+    if (t.viewf_w.size() != (size_t)VW * W) return -4;
+    out.assign((size_t)T::TOTAL, 0);
+    auto comp_pair = [](float wv, uint16_t& p0, uint16_t& p1) {
+        const double wd = (double)wv / COMP_S;
+        const double w1 = f16_to_f32(f32_to_f16((float)wd));
+        p0 = f32_to_f16((float)((COMP_S - 1) * w1));
+        p1 = f32_to_f16((float)(w1 + COMP_S * (wd - w1)));
+    };
+    auto put = [&](size_t frag0, int lane, int e, float wv) {       // planes at frag0 and frag0 + FRAG
+        uint16_t p0, p1;
+        comp_pair(wv, p0, p1);
+        std::memcpy(&out[frag0 + lane * 16 + e * 2], &p0, 2);
+        std::memcpy(&out[frag0 + T::FRAG + lane * 16 + e * 2], &p1, 2);
+    };
+    // trunk sections: `xseq` = the density input in X16 order, else the previous activation (hseq16_channel) at column `colbase`
+    auto trunk = [&](size_t off, int mat, int nu, bool xseq, int colbase) {
+        for (int u = 0; u < nu; ++u)
+            for (int w = 0; w < T::NW; ++w)
+                for (int tt = 0; tt < 2; ++tt) {
+                    const size_t f0 = off + ((size_t)(u * T::NW + w) * 4 + tt * 2) * T::FRAG;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int g = lane >> 4, row = lane & 15;
+                            const int ch = xseq ? xseq16_channel(8 * u + e, g) : hseq16_channel(8 * u + e, g);
+                            if (ch < 0) continue;
+                            put(f0, lane, e, t.w(mat, 16 * (2 * w + tt) + row, colbase + ch));
+                        }
+                }
+    };
+    trunk(T::OFF_X0, MAT_L0, XU16, true, 0);
+    for (int hs = 0; hs < 7; ++hs) trunk(T::OFF_HID(hs), MAT_L0 + 1 + hs, HU16, false, hs == 4 ? CH_X : 0);
+    trunk(T::OFF_X5, MAT_L0 + 5, XU16, true, 0);
+    for (int u = 0; u < HU16; ++u)                      // folded view layer, trunk part: tile pair v = tiles 2 v, 2 v + 1
+        for (int v = 0; v < 4; ++v)
+            for (int tt = 0; tt < 2; ++tt) {
+                const size_t f0 = T::OFF_AV + ((size_t)(u * 4 + v) * 4 + tt * 2) * T::FRAG;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e)
+                        put(f0, lane, e, t.w(MAT_VIEWF, 16 * (2 * v + tt) + (lane & 15), hseq16_channel(8 * u + e, lane >> 4)));
+            }
+    for (int s = 0; s < J + (fc ? 1 : 0); ++s)          // direction part: B fragments [slot][out tile16]
+        for (int tt = 0; tt < NTV16; ++tt) {
+            const size_t f0 = T::OFF_Y + ((size_t)(s * NTV16 + tt) * 2) * T::FRAG;
+            const int j = s < J ? slot16_joint(s) : JC;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = vd_channel(j, 8 * (lane >> 4) + e);
+                    if (ch < 0) continue;
+                    put(f0, lane, e, t.w(MAT_VIEW, 16 * tt + (lane & 15), W + ch));
+                }
+        }
+    auto put_small = [&](size_t base, size_t plane_stride, int e, float wv) {
+        uint16_t p0, p1;
+        comp_pair(wv, p0, p1);
+        std::memcpy(&out[base + e * 2], &p0, 2);
+        std::memcpy(&out[base + plane_stride + e * 2], &p1, 2);
+    };
+    for (int u = 0; u < HU16; ++u)                      // alpha: entry g of [u][plane] = row 0, k = 8 g + e
+        for (int g = 0; g < 4; ++g)
+            for (int e = 0; e < 8; ++e)
+                put_small(T::OFF_SMALL + (size_t)(u * 2) * T::ALPHA_STRIDE + g * 16, T::ALPHA_STRIDE, e, t.w(MAT_ALPHA, 0, hseq16_channel(8 * u + e, g)));
+    for (int u = 0; u < VW / 32; ++u)                   // rgb: entry 3 g + row of [u][plane]
+        for (int g = 0; g < 4; ++g)
+            for (int row = 0; row < 3; ++row)
+                for (int e = 0; e < 8; ++e)
+                    put_small(T::OFF_SMALL + T::SMALL_ALPHA + (size_t)(u * 2) * T::RGB_STRIDE + (3 * g + row) * 16, T::RGB_STRIDE, e,
+                              t.w(MAT_RGB, row, hseq16_channel(8 * u + e, g)));
+    return 0;
+}
+
 void pack_bias_s(const NetTensors& t, std::vector<float>& out) {
     out.assign(BIAS16_FLOATS, 0.f);
     auto put = [&](int tile, const float* b, int n, int row0) {

@@ -42,6 +42,9 @@ void pack_bias(const NetTensors& t, std::vector<float>& out);
 // weights behind layer 0 ([joint slot 6 g + jj][out tile16 t], k = the joint's 27 view values: vd_channel)
 int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out, bool onchip = false);
 void pack_bias_s(const NetTensors& t, std::vector<float>& out);
+// weights of the compensated kernel with the out tiles split over the waves (pg_evalc2.hip; pg_program.h T): fragments
+// addressed directly, no stream; the 16-row bias table (pack_bias_s) goes with it
+int pack_c2(const NetTensors& t, bool framecode, std::vector<uint8_t>& out);
 // Y-stage weights of the record kernel (pg_rayrec.hip): [wave 8][unit n][64 lanes x 16 B]; unit n of
 // wave w = (joint slot16_joint(vy_slot(w, n/2)), k-unit n%2) of out tile w&3 as an MFMA B operand.
 int pack_vy(const NetTensors& t, int precision, bool framecode, std::vector<uint8_t>& out);

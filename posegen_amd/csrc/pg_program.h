@@ -138,4 +138,47 @@ constexpr int C_L5XR_OC = C_L5XR + NPAIRJ;              // 67
 static_assert(4 * NTV == PPC, "a joint pair's direction weights (4 k-units x 4 out tiles) are exactly one chunk");
 }  // namespace C
 
+// ---------------- shape T: compensated fp16 with the OUT TILES split over the waves (pg_evalc2.hip) ----------------
+// No stream and no ring: a workgroup of NW = 8 waves (two per SIMD) carries PTS = 128 points through the net together,
+// wave w computing out channels 32 w .. 32 w + 31 (two 16-row tiles of v_mfma_f32_16x16x32_f16) of every layer for all
+// of them; the layer's input -- the split fp16 pairs of the activations -- lives in LDS as B fragments
+// [k-unit u][column tile c][plane][lane (g, col)] x 16 B (1 KiB each; k-unit u of the next layer = wave u's two tiles,
+// hseq16_channel), and every wave reads its OWN quarter-KiB-per-lane of weights straight from L2 into registers:
+// fragment (1 KiB: lane (g, row) = out row, k = 8 g + e) [k-unit][wave][tile t of the wave (2)][plane (2)], so that one
+// k-unit of one wave is KBLK = 4 KiB contiguous.  Plane 0 = (S-1) w1, plane 1 = w2 (pg_pack.cpp comp_pair).
+//   X0  | H1 H2 H3 H4 H5 | X5 | H6 H7 | AV | Y | SMALL
+//   X*: the density input in the X16 sequence of pg_layout.h (15 k-units: 6 limbs x 2, then 3 of directions)
+//   H*: trunk layers 1..7 on the previous activation (8 k-units)
+//   AV: the folded view layer's trunk part, [k-unit][tile pair v (4)][t][plane]: waves v and v + 4 (column tiles 0..3 / 4..7)
+//   Y : the view layer's direction (and frame-code) weights as B fragments [joint slot s (24 + code)][out tile16 (8)][plane]:
+//       lane (g, col) = out channel 16 t + col, k = 8 g + e of the slot's 27 (16) values (vd_channel)
+//   SMALL: the alpha row and the three rgb rows as compact A fragments (only lanes of rows 0 / 0..2 are non-zero):
+//       alpha [k-unit 8][plane][5 x 16 B: g = 0..3, zero], rgb [k-unit 4][plane][13 x 16 B: (g, row < 3), zero]
+namespace T {
+constexpr int NW = 8;
+constexpr int PTS = 128;
+constexpr int NCT = PTS / 16;                 // 8 column tiles
+constexpr int MAXR = 5;                       // rays a pass can touch (samples per ray >= MIN_S)
+constexpr int MIN_S = 32;
+constexpr int FRAG = 1024;
+constexpr int KBLK = 4 * FRAG;
+constexpr int SEC_X = XU16 * NW * KBLK;       // 480 KiB
+constexpr int SEC_H = HU16 * NW * KBLK;       // 256 KiB
+constexpr int SEC_AV = HU16 * 4 * KBLK;       // 128 KiB
+constexpr int NSLOT_Y = J + 1;
+constexpr int SEC_Y = NSLOT_Y * NTV16 * 2 * FRAG;       // 400 KiB
+constexpr int ALPHA_STRIDE = 5 * 16, RGB_STRIDE = 13 * 16;
+constexpr int SMALL_ALPHA = HU16 * 2 * ALPHA_STRIDE;    // 1280
+constexpr int SMALL_RGB = (VW / 32) * 2 * RGB_STRIDE;   // 1664
+constexpr int OFF_X0 = 0;
+constexpr int OFF_HID(int hs) { return SEC_X + hs * SEC_H + (hs >= 5 ? SEC_X : 0); }   // hs = 0..6: layers 1..7
+constexpr int OFF_X5 = SEC_X + 5 * SEC_H;
+constexpr int OFF_AV = OFF_HID(7);
+constexpr int OFF_Y = OFF_AV + SEC_AV;
+constexpr int OFF_SMALL = OFF_Y + SEC_Y;
+constexpr int TOTAL = OFF_SMALL + SMALL_ALPHA + SMALL_RGB;
+// 16x16x32 MFMAs per 128-point pass with every limb in range (pg_query / roofline bookkeeping)
+constexpr int MFMA16_PER_PASS = NW * (2 * XU16 * 32 + 7 * HU16 * 32) + NW * (HU16 * 16 + HU16 * 2) + NW * 16 + NW * 8;
+}  // namespace T
+
 }  // namespace pgp

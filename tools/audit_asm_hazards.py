@@ -13,6 +13,12 @@ transcendental operation (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos
 hipcc pads its own instructions but does not look inside inline asm: `v_cos_f32 v141, ..` directly followed by an
 inline-asm `v_cvt_pk_f16_f32 .., v141` read stale values in the first lanes of the wave (the on-chip form of the
 compensated kernel, first build: Y of lanes 0..15 off by 1 %).  The audit fails on any such adjacent pair.
+
+Third check (round 5): "VALU writes an SGPR -> a vector-memory instruction reads it" needs five wait states on gfx9-family
+parts.  hipcc pads its own memory instructions, not those inside inline asm: a `v_readlane_b32 s9, ..` (the reload of a spilled
+SGPR) directly in front of an inline-asm `global_load_dwordx4 .., s[8:9]` made the first build of pg_evalc2.hip fault on
+an address with a stale upper half.  The audit fails when an inline-asm vector-memory instruction reads an SGPR that a
+VALU instruction (v_readlane / v_readfirstlane / a compare or carry writing an SGPR) wrote fewer than five wait states before.
 usage: audit_asm_hazards.py kernel.s"""
 import re
 import sys
@@ -44,6 +50,58 @@ def trans_hazards(kernel_text):
         prev = int(m.group(1)) if m else None
     return hits
 
+
+def sregs(tok):
+    m = re.match(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"s(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+VMEM = re.compile(r"\s*(global_|buffer_|flat_|scratch_)")
+
+
+def sgpr_vmem_hazards(kernel_text):
+    """inline-asm vector-memory instructions that read an SGPR written by a VALU instruction < 5 wait states earlier"""
+    hits = []
+    recent = []                 # (wait states ago, set of SGPRs written by a VALU instruction)
+    in_asm = False
+    for ln in kernel_text.split("\n"):
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        code = ln.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        toks = [t for t in re.split(r"[,\s]+", code) if t]
+        if in_asm and VMEM.match(code):
+            srcs = set()
+            for t in toks[1:]:
+                srcs |= sregs(t)
+            for age, regs in recent:
+                if age < 5 and regs & srcs:
+                    hits.append(code)
+                    break
+        states = 1
+        m = re.match(r"s_nop\s+(\d+)", code)
+        if m:
+            states = int(m.group(1)) + 1
+        recent = [(a + states, r) for a, r in recent if a + states < 5]
+        if code.startswith("v_"):
+            written = set()
+            if toks[0].startswith(("v_readlane", "v_readfirstlane")):
+                written = sregs(toks[1])
+            elif len(toks) > 1:
+                written = sregs(toks[1]) | (sregs(toks[2]) if toks[0].startswith(("v_add_co", "v_sub_co", "v_addc", "v_subb", "v_div_scale", "v_mad_u64", "v_mad_i64")) and len(toks) > 2 else set())
+            if written:
+                recent.append((0, written))
+    return hits
+
+
 txt = open(sys.argv[1]).read()
 bad = 0
 for k in re.split(r'\n(?=_Z\w+:)', txt):
@@ -60,5 +118,9 @@ for k in re.split(r'\n(?=_Z\w+:)', txt):
     for t in th[:5]:
         print(f"   transcendental result read by the next instruction: {t}")
     bad += len(th)
+    sh = sgpr_vmem_hazards(k)
+    for t in sh[:5]:
+        print(f"   inline-asm memory instruction reads an SGPR a VALU instruction has just written: {t}")
+    bad += len(sh)
 print("HAZARD AUDIT", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
