@@ -19,6 +19,12 @@ parts.  hipcc pads its own memory instructions, not those inside inline asm: a `
 SGPR) directly in front of an inline-asm `global_load_dwordx4 .., s[8:9]` made the first build of pg_evalc2.hip fault on
 an address with a stale upper half.  The audit fails when an inline-asm vector-memory instruction reads an SGPR that a
 VALU instruction (v_readlane / v_readfirstlane / a compare or carry writing an SGPR) wrote fewer than five wait states before.
+
+Fourth check (round 5): "XDL (MFMA) writes a VGPR -> a VALU instruction reads it" needs (passes + 2 + 1) wait states on gfx950:
+7 behind a 4-pass MFMA (16x16x32), 11 behind an 8-pass one (32x32x16).  hipcc pads its own VALU instructions; an inline-asm
+conversion block scheduled 5 instructions behind the last MFMA of its accumulator read it stale (pg_evalc2.hip, the first
+build with conversions between the MFMA blocks: one column tile off by a few percent).  The audit fails when an inline-asm
+VALU instruction reads a register an MFMA wrote fewer than 8 / 12 wait states before.
 usage: audit_asm_hazards.py kernel.s"""
 import re
 import sys
@@ -102,6 +108,46 @@ def sgpr_vmem_hazards(kernel_text):
     return hits
 
 
+
+def mfma_valu_hazards(kernel_text):
+    """inline-asm VALU instructions that read (or overwrite) a VGPR an MFMA wrote too few wait states earlier.
+    Timing model: every instruction takes one issue slot (s_nop N: N + 1); an MFMA that follows another within its
+    passes waits for the matrix pipe (4 slots behind a 16x16x32, 8 behind a 32x32x16), a VALU instruction does not."""
+    hits = []
+    ready = {}                  # vgpr -> first slot at which a VALU instruction may touch it
+    t, pipe_free = 0, 0
+    in_asm = False
+    for ln in kernel_text.split("\n"):
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        code = ln.split(";")[0].strip()
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        toks = [t_ for t_ in re.split(r"[,\s]+", code) if t_]
+        m = re.match(r"s_nop\s+(\d+)", code)
+        if toks[0].startswith("v_mfma"):
+            t = max(t + 1, pipe_free)
+            passes = 8 if "32x32" in toks[0] else 4
+            pipe_free = t + passes
+            for r in vregs(toks[1]):
+                ready[r] = t + passes + 3 + 1         # passes + 2 (+ 1 on gfx950) wait states, and one of margin
+            continue
+        t += int(m.group(1)) + 1 if m else 1
+        if code.startswith("v_"):
+            touched = set()
+            for t_ in toks[1:]:
+                touched |= vregs(t_)
+            if in_asm and any(ready.get(r, 0) > t for r in touched):
+                hits.append(code)
+            for r in vregs(toks[1]):
+                ready.pop(r, None)
+    return hits
+
+
 txt = open(sys.argv[1]).read()
 bad = 0
 for k in re.split(r'\n(?=_Z\w+:)', txt):
@@ -122,5 +168,9 @@ for k in re.split(r'\n(?=_Z\w+:)', txt):
     for t in sh[:5]:
         print(f"   inline-asm memory instruction reads an SGPR a VALU instruction has just written: {t}")
     bad += len(sh)
+    mh = mfma_valu_hazards(k)
+    for t in mh[:5]:
+        print(f"   inline-asm VALU instruction reads an MFMA result too early: {t}")
+    bad += len(mh)
 print("HAZARD AUDIT", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
