@@ -83,13 +83,14 @@ def self_launch(a) -> int:
     return 0
 
 
-def full_frame_rays(H, W, device, cfg=None):
+def full_frame_rays(H, W, device, cfg=None, sigma=0.2):
     """All H*W rays of the synthetic camera, cylinder radius 2.5 so that every ray hits
-    (SURVEY.md 8(d) 'full' variant).  Ray formula of the reference's get_rays."""
+    (SURVEY.md 8(d) 'full' variant).  Ray formula of the reference's get_rays.  sigma: spread of the pose's joint
+    angles (0.2 = the headline pose of SURVEY.md 8(d))."""
     import torch
     from posegen_amd import synthetic as syn
     from posegen_amd.skeleton import get_kp_bounding_cylinder
-    _, kps, skts = syn.make_pose(1, 1)
+    _, kps, skts = syn.make_pose(1, 1, sigma=sigma)
     c2ws, focals = syn.make_camera(1, H, W)
     c2w = torch.tensor(c2ws[0])
     f = float(focals[0])
@@ -260,8 +261,8 @@ def train_step_rate(dev, n_rand=4096, steps=5, warmup=2, precision="fp32"):
     from posegen_amd.raycaster import HipRayCaster
     from posegen_amd.train import TrainableRayCaster
     cfg = surreal_config()
-    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=dev, precision=precision)
-    m = TrainableRayCaster(c)
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=dev, precision="bf16")
+    m = TrainableRayCaster(c, train_precision=precision)    # (the training step's arithmetic; the rendering precision plays no part)
     m.train()
     rb, skts, cyl, *_ = full_frame_rays(512, 512, dev)
     sel = torch.linspace(0, rb.shape[0] - 1, n_rand, device=dev).long()
@@ -469,7 +470,7 @@ def main():
     rays_s = (strong_state["valid"] if strong else world * n) * a.steps / dt
     peak = PEAK_TFLOPS[a.prec]
     k_tflops = k_pts * flops_pt / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    kernel = {"bf16": "eval16r_kernel", "fp16": "eval16r_kernel", "fp16c": "evalc_kernel"}.get(a.prec, "eval32_kernel")
+    kernel = {"bf16": "eval16r_kernel", "fp16": "eval16r_kernel", "fp16c": "evalc2_kernel"}.get(a.prec, "eval32_kernel")
     result = {
         "metric": METRIC,
         "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -517,38 +518,70 @@ def main():
     if di["clock_khz"] > 0 and a.prec != "fp32":
         result["roofline"]["peak_derived"] = di["n_cu"] * 4 * 1024 * di["clock_khz"] * 1e3 / 1e12
         result["roofline"]["peak_derived_from"] = f"{di['n_cu']} CUs x 4096 FLOP/clk x {di['clock_khz'] / 1e6:.2f} GHz (hipDeviceProp)"
-    # `achieved` counts the ALGORITHMIC flops of the reference network.  The 16-bit
-    # kernels execute fewer: feature_linear is folded into the view layer and the view-direction
-    # input is factorised over rays, both exact in real arithmetic.  The MFMA
-    # flops actually issued are reported beside it.
+    # `achieved` counts the ALGORITHMIC flops of the reference network.  The kernels ISSUE fewer: feature_linear
+    # is folded into the view layer, the view-direction input is factorised over rays (both exact in real arithmetic), and the
+    # limbs of the cutoff embedding that are out of range of a wave / a pass are left out (products below 2^-24 of a value:
+    # DESIGN.md 2.1) -- which depends on the pose, tau and the cutoff.  So the line carries its conditions:
+    #   issued_frac       MFMA FLOPs really issued per launch (SQ_INSTS_MFMA of the committed PMC pass of this workload)
+    #                     over the algorithmic FLOPs
+    #   limb_masks        what the kernel itself counts on the coarse launch of this frame (pg_stage_eval, stage 97)
+    #   far_skip_off      the same steps with pg_set_far_skip(0): every limb computed for every point
+    #   folded_pose       the same frame size with the pose's joint angles drawn three times as wide (limbs folded towards
+    #                     the trunk: more limbs in range of a point)
+    mfma_flop = 4096 if a.prec == "fp32" else 16384 if a.prec in ("bf16", "fp16", "fp16c") else 32768
+    for tname in (f"r5_{a.prec}_traffic.json", f"r4_{a.prec}_traffic.json"):
+        tpath = os.path.join(REPO, "profiles", tname)
+        if H == 512 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            ins = tj.get("counters_per_launch", {}).get("SQ_INSTS_MFMA")
+            if ins:
+                per = 16384 if ("eval16r" in tj["kernel"] or "evalc2" in tj["kernel"]) else 32768
+                result["roofline"]["issued_frac"] = ins * per / (k_pts / max(launches, 1) * flops_pt)
+                result["roofline"]["issued_from"] = (f"SQ_INSTS_MFMA {ins:.4g} per launch x {per} FLOP (profiles/{tname}, commit "
+                                                     f"{tj.get('commit', 'unrecorded')}) over points per launch x {flops_pt} algorithmic FLOP")
+            break
+    if a.prec in ("bf16", "fp16", "fp16c") and world == 1:
+        nf, z = r.stage_sample_coarse(rb, cyl, cfg.n_samples)
+        result["roofline"]["limb_masks"] = dict(r.limb_skip_stats(0, rb, z, skts),
+                                                what=f"coarse launch of the benchmark frame ({cfg.n_samples} samples per ray), counted by the kernel: "
+                                                     "limbs_left_out_frac of the (wave / 16-point column tile, limb) pairs skip embedding and MFMAs, "
+                                                     "limbs_left_out_of_whole_passes_frac of the (pass, limb) pairs also skip the weight fetch; "
+                                                     f"tau = {float(model[2]):.1f}, cutoff 0.5")
+        r.set_far_skip(False)
+        _, _, tf_off, kms_off = timed_rays(r, dev, rb, skts, cyl, cfg, max(2, a.steps // 4))
+        r.set_far_skip(True)
+        result["roofline"]["far_skip_off"] = {"avg_launch_ms": kms_off, "frac": tf_off / peak,
+                                              "what": "the same frame with pg_set_far_skip(0): no limb masks"}
+        rb2, skts2, cyl2, *_ = full_frame_rays(H, W, dev, sigma=0.6)
+        rs2, msf2, tf2, kms2 = timed_rays(r, dev, rb2, skts2, cyl2, cfg, max(2, a.steps // 4))
+        nf2, z2 = r.stage_sample_coarse(rb2, cyl2, cfg.n_samples)
+        result["roofline"]["folded_pose"] = {"rays_per_s": rs2, "ms_per_frame": msf2, "avg_launch_ms": kms2, "frac": tf2 / peak,
+                                             "limb_masks": r.limb_skip_stats(0, rb2, z2, skts2),
+                                             "what": "same frame size and camera, joint angles ~ N(0, 0.6^2) instead of N(0, 0.2^2)"}
     q = r.query()
-    mfma_flop = 4096 if a.prec == "fp32" else 32768
-    ex = q["mfma_per_group"] * mfma_flop / 32.0
-    result["roofline"]["executed_flop_per_point"] = ex
-    result["roofline"]["executed_tflops"] = k_tflops * ex / flops_pt
-    result["roofline"]["executed_frac"] = k_tflops * ex / flops_pt / peak
-    result["roofline"]["executed_note"] = ("executed_* = the kernel's PROGRAM (every limb / joint pair in range): an upper bound since round 4 -- the "
-                                           "MFMAs a launch really issues (limbs out of cutoff range are skipped) are in the committed PMC pass, "
-                                           "SQ_INSTS_MFMA of profiles/r4_*_pmc.csv")
+    result["roofline"]["program_flop_per_point"] = q["mfma_per_group"] * (4096 if a.prec == "fp32" else 32768) / 32.0
+    result["roofline"]["program_note"] = "the kernel's program with every limb in range, in FLOPs per point: an upper bound of what a launch issues"
 
     # What this box SUSTAINS on bare 32x32x16 MFMAs (register operands, 2 waves per SIMD on every CU,
     # nothing else in the loop, one >= 20 ms launch): `peak` stays the nominal dense figure, this says how
     # much of the gap is the chip's clock management under MFMA load rather than the kernel's stalls.
     if a.prec != "fp32" and world == 1:
         # the shape of the kernel that ran: 16x16x32 for the 16-bit modes (pg_eval16r.hip), 32x32x16 for the compensated one
-        small = 2 if a.prec in ("bf16", "fp16") else 0
+        small = 2 if a.prec in ("bf16", "fp16", "fp16c") else 0
         shape = "16x16x32" if small else "32x32x16"
         f16 = a.prec != "bf16"
         cal = r.calibrate_mfma(f16=f16, lds_fed=small)
         result["roofline"]["sustained_mfma_tflops"] = cal["tflops"]
         result["roofline"]["sustained_mfma_from"] = (f"bare v_mfma_f32_{shape}_{'f16' if f16 else 'bf16'} loop (the kernel's MFMA shape), "
                                                      f"{cal['ms']:.1f} ms launch on this box (pg_calibrate_mfma)")
-        result["roofline"]["executed_frac_of_sustained"] = result["roofline"]["executed_tflops"] / cal["tflops"]
+        if "issued_frac" in result["roofline"]:
+            result["roofline"]["issued_frac_of_sustained"] = k_tflops * result["roofline"]["issued_frac"] / cal["tflops"]
         # the same loop with the A operand of every MFMA read from LDS (one ds_read_b128 per MFMA and wave):
         # the ceiling of the kernels' structure -- weight fragments from the LDS ring
         cal2 = r.calibrate_mfma(f16=f16, lds_fed=small | 1)
         result["roofline"]["sustained_mfma_lds_fed_tflops"] = cal2["tflops"]
-        result["roofline"]["executed_frac_of_lds_fed"] = result["roofline"]["executed_tflops"] / cal2["tflops"]
+        if "issued_frac" in result["roofline"]:
+            result["roofline"]["issued_frac_of_lds_fed"] = k_tflops * result["roofline"]["issued_frac"] / cal2["tflops"]
         if small:       # what the chip sustains on the other shape (round 2's kernel): the reason for the re-layout
             cal3 = r.calibrate_mfma(f16=f16, lds_fed=0)
             result["roofline"]["sustained_mfma_32x32x16_tflops"] = cal3["tflops"]
@@ -557,7 +590,7 @@ def main():
     # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); bench.py cannot run the
     # profiler on itself, so the committed measurement of the same build is attached.
     alg_bytes = 20 * k_pts / max(launches, 1)       # z in 4 B/point + raw out 16 B/point
-    for tname in (f"r4_{a.prec}_traffic.json", f"r3_{a.prec}_traffic.json", f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
+    for tname in (f"r5_{a.prec}_traffic.json", f"r4_{a.prec}_traffic.json", f"r3_{a.prec}_traffic.json", f"r2_{a.prec}_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(REPO, "profiles", tname)
         if H == 512 and os.path.exists(tpath) and (a.prec == "bf16" or not tname.startswith("r1_")):
             tj = json.load(open(tpath))
@@ -650,6 +683,11 @@ def main():
                         f"{c4.evals_per_ray()} MLP evals/ray, per-ray frame-code index, view layer K = {c4.ch_view_in}",
             "rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / peak, "avg_launch_ms": kms,
             "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
+        if a.prec != "fp16c":       # BASELINE config 4 in the north-star mode as well (no per-ray records since round 5: pg_evalc2.hip)
+            cast4.renderer.set_precision("fp16c")
+            rs, msf, tf, kms = timed_rays(cast4.renderer, dev, rb, skts, cyl, c4, 1, cams=cams)
+            result["workloads"]["h36m_512_fp16c"] = {"rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / PEAK_TFLOPS["fp16c"],
+                                                     "avg_launch_ms": kms, "what": "the same frame in the compensated-fp16 mode"}
         cast4.renderer.close()
         result["train_step"] = train_step_rate(dev, precision="bf16")
         result["train_step"]["fp32"] = train_step_rate(dev, precision="fp32")

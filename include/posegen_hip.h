@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7
+#define PG_ABI_VERSION 8
 
 /* error codes */
 #define PG_OK 0
@@ -348,7 +348,11 @@ int pg_stage_sample_coarse(pg_handle* h, void* stream, int64_t n, const float* r
  * layer 1..7 (post-ReLU); 8 = feature_linear output; 9 = view layer output (128 used);
  * 10 = view cutoff weights wd (24 used); 11 = the first 16 units of view-layer input values as
  * the MFMA sees them; 12..17 = floats 64(s-12).. of the lane half's view table as found in LDS at the
- * end of the pass.  Stages > 0 are only honoured by the fp32-grade kernels (PG_PREC_FP32 / *X3). */
+ * end of the pass.  Stages > 0 are only honoured by the fp32-grade kernels (PG_PREC_FP32 / *X3).
+ * dbg_stage 97 (measurement aid; the 16-bit and compensated modes on rays with >= 64 samples): dbg is an array of >= 3
+ * ZEROED unsigned counters instead, to which the launch adds: [0] workgroup passes, [1] limbs left out of whole passes
+ * (of 6 per pass), [2] limbs left out per wave / column tile (of 48 per pass) -- what the cutoff embedding's limb masks
+ * (pg_set_far_skip) are worth on this call. */
 int pg_stage_eval(pg_handle* h, void* stream, int which_net, int64_t n, int n_samples,
                   const float* ray_batch, const float* z, const float* skts,
                   int64_t pose_stride, const float* cams, float* raw, float* dbg, int dbg_stage);
@@ -374,6 +378,12 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
  * cutoff_dist + 24 / (tau log2 e) has a cutoff weight 1 - sigmoid(tau (v - c)) below 2^-24, cutoff_embedder.py:139-146:
  * DESIGN.md 2.1).  Default on.  The two settings agree to ~1e-7 per skipped product. */
 int pg_set_far_skip(pg_handle* h, int on);
+
+/* Arithmetic of the TRAINING step (pg_train_forward / pg_train_backward), independent of the rendering precision
+ * (pg_set_precision): PG_PREC_FP32 (default; the reference trains in fp32, core/trainer.py:232-275: gradients within 1e-4
+ * of its autograd) or PG_PREC_BF16 (the tape and the large GEMMs' operands in bf16, fp32 accumulate: opt-in).  The mode is
+ * read by pg_train_forward and recorded on the tape: a tape's backward runs in the mode its forward ran in. */
+int pg_set_train_precision(pg_handle* h, int precision);
 
 /* Optional in-library timing of the fused embed+MLP kernel (the dominant kernel): while
  * enabled, every launch is bracketed by hipEvents on the caller's stream.  pg_profile_read

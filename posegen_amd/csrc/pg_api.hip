@@ -347,9 +347,9 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
     const bool fc = h->cfg.framecode_ch > 0;
-    const bool onchip = sa && fact && !dbg && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records
+    const bool onchip = sa && fact && (!dbg || dbg_stage == 97) && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
-    const bool c2 = compk && (!dbg || dbg_stage == 99) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
+    const bool c2 = compk && (!dbg || dbg_stage == 99 || dbg_stage == 97) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
     const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
     const bool crec = !c2 && compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec) : c2 ? ensure_c2(h, which)
@@ -718,6 +718,15 @@ int pg_set_far_skip(pg_handle* h, int on) {
     return PG_OK;
 }
 
+int pg_set_train_precision(pg_handle* h, int precision) {
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
+    if (precision != PG_PREC_FP32 && precision != PG_PREC_BF16)
+        return pg_fail(h, PG_EINVAL, "pg_set_train_precision: the training step computes in fp32 (PG_PREC_FP32) or on a bf16 tape (PG_PREC_BF16), not %d", precision);
+    h->train_precision = precision;
+    for (pg_handle* p : h->peers) p->train_precision = precision;
+    return PG_OK;
+}
+
 int pg_profile_enable(pg_handle* h, int on) {
     if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_profile_enable: null handle");
     h->profiling = on != 0;
@@ -886,6 +895,11 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
         if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
+        return PG_OK;
+    }
+    if (compk && use_evalc2(FACT_MIN_S)) {       // out tiles over the waves (pg_evalc2.hip): no stream; 16x16x32 MFMAs in 32x32x16 equivalents
+        if (stream_bytes) *stream_bytes = (int64_t)pgp::T::TOTAL;
+        if (mfma_per_group) *mfma_per_group = pgp::T::MFMA16_PER_PASS / 2 / (pgp::T::PTS / 32);
         return PG_OK;
     }
     if (compk && use_comp_rec(FACT_MIN_S)) {     // record variant of the compensated kernel (the usual case)

@@ -341,7 +341,9 @@ __device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds,
 // records in HBM and no record kernel in front.  The (a, b) rows of a pass's rays are formed by the workgroup a pass
 // ahead from the rays themselves (LDS-DMA of their ray_batch rows and first / last depths, the pose's bone rows kept in
 // LDS), and the view layer's direction part Y by y_segment16 from limb chunks of the weight stream.
-template <typename V, bool FC, bool TAPS, bool OC>
+// CNT (measurement aid, dbg_stage 97; its own instantiation): passes, limbs left out of whole passes (of 6 per pass) and
+// limbs left out per wave (of 48 per pass), summed over the launch into a.dbg[0..2] (unsigned)
+template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false>
 __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     static_assert(!(OC && FC), "the on-chip variant has no frame-code pseudo joint");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -475,6 +477,10 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             farmask = __builtin_amdgcn_readfirstlane(a.far_skip ? farmask : 0);
         }
 #endif
+        if (CNT && lane == 0) {
+            if (wave == 0) { atomicAdd(reinterpret_cast<unsigned*>(a.dbg), 1u); atomicAdd(reinterpret_cast<unsigned*>(a.dbg) + 1, (unsigned)__builtin_popcount(gmask)); }
+            atomicAdd(reinterpret_cast<unsigned*>(a.dbg) + 2, (unsigned)__builtin_popcount(farmask));
+        }
         // Behind layer 0's first chunk entry every wave is done with the previous pass: its Y records and the
         // (a, b) buffer of the pass before may be overwritten.  Wave w fetches out tile w of this pass's MAXR_F Y
         // records and waves 0..3 a piece of the NEXT pass's (a, b); both are in LDS, and visible, one chunk entry on.
@@ -668,9 +674,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC, bool TAPS, bool OC>
+template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false>
 static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16r_kernel<V, FC, TAPS, OC>;
+    auto k = eval16r_kernel<V, FC, TAPS, OC, CNT>;
     constexpr int lds = OC ? LDSR_TOTAL_OC : LDSR_TOTAL;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
     const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), lds, attr_done);
@@ -681,6 +687,7 @@ static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream
 
 template <typename V>
 static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip, int grid, hipStream_t s) {
+    if (onchip && a.dbg && a.dbg_stage == 97) return launch_eval16r<V, false, false, true, true>(a, grid, s);      // the limb-mask counters
     const bool taps = a.dbg && a.dbg_stage != 99;
     if (onchip) return taps ? hipErrorInvalidValue : launch_eval16r<V, false, false, true>(a, grid, s);     // (no debug taps in this variant)
     if (taps) return framecode ? launch_eval16r<V, true, true, false>(a, grid, s) : launch_eval16r<V, false, true, false>(a, grid, s);

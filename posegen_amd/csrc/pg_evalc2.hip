@@ -395,6 +395,10 @@ __global__ __launch_bounds__(NTHR2, 2) void evalc2_kernel(const EvalArgs a) {
     if ((int)blockIdx.x < a.n_iters) nx_z = a.z[min(p0 + 16 * wave + col, a.n_points - 1)];
     lds_barrier();
 
+    // dbg_stage 97: passes, limbs left out of whole passes (of 6 per pass), (column tile, limb) pairs left out (of 48 per pass),
+    // summed over the launch into a.dbg[0..2] (unsigned)
+    const bool count_skips = a.dbg != nullptr && a.dbg_stage == 97;
+    unsigned n_cnt[3] = {0u, 0u, 0u};
     // per-wave constants of the pass loop
     const uint8_t* wx_wave = wbase + wave * TT::KBLK;       // + section + k-unit * NW * KBLK
     WPair W[4];
@@ -458,6 +462,12 @@ __global__ __launch_bounds__(NTHR2, 2) void evalc2_kernel(const EvalArgs a) {
         int gmask = 63;
 #pragma unroll
         for (int c = 0; c < TT::NCT; ++c) gmask &= cm[c];
+        if (count_skips && tid == 0) {       // (measurement aid, dbg_stage 97: what the limb masks leave out)
+            n_cnt[0] += 1;
+            n_cnt[1] += __builtin_popcount(gmask);
+#pragma unroll
+            for (int c = 0; c < TT::NCT; ++c) n_cnt[2] += __builtin_popcount(cm[c]);
+        }
         // the limbs in range of the pass, in order: nibble k of `ll`
         int nl = 0;
         unsigned ll = 0;
@@ -957,6 +967,8 @@ __global__ __launch_bounds__(NTHR2, 2) void evalc2_kernel(const EvalArgs a) {
     if (a.dbg && a.dbg_stage == 99 && lane == 0)
         for (int k = 0; k < 12; ++k) reinterpret_cast<unsigned long long*>(a.dbg)[((long long)blockIdx.x * TT::NW + wave) * 16 + k] = stamp_acc[k];
 #endif
+    if (count_skips && tid == 0)
+        for (int k = 0; k < 3; ++k) atomicAdd(reinterpret_cast<unsigned*>(a.dbg) + k, n_cnt[k]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -975,10 +987,10 @@ static hipError_t launch(const EvalArgs& a, int grid, hipStream_t stream) {
 
 // needs S >= pgp::T::MIN_S, rays (no explicit points, no position noise), the shape-T weights (pack_c2) in a.wstream and the
 // 16-row bias table (pack_bias_s) in a.bias; any pose stride; frame codes when `framecode`; no debug taps (a.dbg only
-// receives the stamps of a PG_STAMPS build, stage 99)
+// receives the stamps of a PG_STAMPS build, stage 99, or the limb-mask counters, stage 97)
 extern "C" int pg_launch_evalc2(const pgd::EvalArgs* a, int framecode, int grid, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a->S < pgp::T::MIN_S || a->pts || a->pnoise || (a->dbg && a->dbg_stage != 99)) return (int)hipErrorInvalidValue;
+    if (a->S < pgp::T::MIN_S || a->pts || a->pnoise || (a->dbg && a->dbg_stage != 99 && a->dbg_stage != 97)) return (int)hipErrorInvalidValue;
     const bool pp = a->pose_stride != 0;
     if (framecode) return (int)(pp ? pgd::c2::launch<true, true>(*a, grid, s) : pgd::c2::launch<true, false>(*a, grid, s));
     return (int)(pp ? pgd::c2::launch<false, true>(*a, grid, s) : pgd::c2::launch<false, false>(*a, grid, s));

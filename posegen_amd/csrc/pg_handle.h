@@ -57,6 +57,7 @@ struct pg_handle {
     hipStream_t own_stream = nullptr;
     float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
     bool far_skip = true;            // pg_set_far_skip (test / measurement aid)
+    int train_precision = PG_PREC_FP32;      // pg_set_train_precision: arithmetic of the training step (fp32 like the reference, or bf16)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;

@@ -178,7 +178,7 @@ constexpr int OFF_Y = OFF_AV + SEC_AV;
 constexpr int OFF_SMALL = OFF_Y + SEC_Y;
 constexpr int TOTAL = OFF_SMALL + SMALL_ALPHA + SMALL_RGB;
 // 16x16x32 MFMAs per 128-point pass with every limb in range (pg_query / roofline bookkeeping)
-constexpr int MFMA16_PER_PASS = NW * (2 * XU16 * 32 + 7 * HU16 * 32) + NW * (HU16 * 16 + HU16 * 2) + NW * 16 + NW * 8;
+constexpr int MFMA16_PER_PASS = NW * (2 * XU16 * 32 + 7 * HU16 * 32 + HU16 * 16 + HU16 * 2 /*alpha*/ + 32 /*second stage*/ + 8 /*rgb*/ + 2 * NSLOT_Y /*Y*/);
 }  // namespace T
 
 }  // namespace pgp

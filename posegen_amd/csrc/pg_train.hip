@@ -13,10 +13,10 @@
 // Training batches are small (N_rand = 2048 rays -> 131 k + 164 k points, configs/surreal/surreal.txt:34), so the
 // 1080-wide embedding and the layer activations are MATERIALISED in HBM (the tape: 14 KB per point in fp32) and every layer
 // is a plain GEMM; the weight gradients split K over the points and are reduced in a fixed order (bitwise repeatable).
-// The fused inference kernels are not involved.  Two modes, by the handle's precision:
+// The fused inference kernels are not involved.  Two modes (pg_set_train_precision; the rendering precision plays no part):
 //   * fp32 (parity with the reference's autograd): v_mfma_f32_32x32x2_f32, 128 x 128 x 16 tiles (sgemm128_kernel), a
 //     64-tile kernel for small and unaligned shapes (sgemm_kernel);
-//   * 16-bit (PG_PREC_BF16): the tape's activations and activation gradients are STORED in bf16 (the embedding rows, the
+//   * 16-bit (PG_PREC_BF16, opt-in): the tape's activations and activation gradients are STORED in bf16 (the embedding rows, the
 //     layer outputs, dH, dG) and the large GEMMs multiply bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32
 //     accumulation (bgemm128_kernel, 128 x 128 x 64 tiles; the weights as bf16 copies made once per step); weights,
 //     biases, raw, d_raw, every weight gradient and the partial sums of the two-part layers stay fp32.
@@ -777,7 +777,7 @@ struct Tape {
     Pass pass[2];
     pg_net_params params[2];
     bool has_fine = false;
-    bool bf16 = false;          // 16-bit training mode (handle precision PG_PREC_BF16): bf16 tape, bf16 operands in the large GEMMs
+    bool bf16 = false;          // 16-bit training mode (pg_set_train_precision PG_PREC_BF16): bf16 tape, bf16 operands in the large GEMMs
     int es() const { return bf16 ? 2 : 4; }                     // bytes per tape element
 };
 inline const void* el_off(const void* p, long long elems, int es) { return static_cast<const uint8_t*>(p) + elems * es; }
@@ -1118,7 +1118,7 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
     const long long Pc = n * S, Pf = N > 0 ? n * SF : 0, Pm = std::max(Pc, Pf);
     const bool rnoise = dr && dr->ray_noise;
     size_t need = al((size_t)n * 44) + al((size_t)n * 4) + al((size_t)n * 8) + al((size_t)n * S * 4) /*w0*/ + al((size_t)n * SF * 4) /*order*/;
-    const bool bf = h->cfg.precision == PG_PREC_BF16;       // 16-bit mode: the tape's activations and their gradients are bf16 arrays
+    const bool bf = h->train_precision == PG_PREC_BF16;     // 16-bit mode (pg_set_train_precision): the tape's activations and their gradients are bf16 arrays
     const size_t es = bf ? 2 : 4;
     auto pass_bytes = [&](long long P) {
         return al((size_t)P * XW * es) + (DEPTH + 1) * al((size_t)P * W * es) + al((size_t)P * VW * es) + al((size_t)P * 16) + 2 * al((size_t)P * 4) + al((size_t)P * 12);

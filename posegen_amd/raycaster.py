@@ -142,6 +142,12 @@ class HipRenderer:
         """Test / measurement aid (pg_set_far_skip): off = the fused kernels compute every limb for every point."""
         self._check(self.lib.pg_set_far_skip(self.handle, 1 if on else 0))
 
+    def set_train_precision(self, precision="fp32"):
+        """Arithmetic of the training step (pg_set_train_precision): "fp32" (the reference's, default) or "bf16" (bf16 tape
+        and GEMM operands); independent of the rendering precision."""
+        p = PREC_BY_NAME[precision] if isinstance(precision, str) else int(precision)
+        self._check(self.lib.pg_set_train_precision(self.handle, p))
+
     def profile_enable(self, on=True):
         self._check(self.lib.pg_profile_enable(self.handle, 1 if on else 0))
 
@@ -495,6 +501,24 @@ class HipRenderer:
         self._check(self.lib.pg_stage_eval(self.handle, self._stream(), int(which), n, S, _ptr(rb), _ptr(zz),
                                            _ptr(sk), ps, _ptr(cam), _ptr(raw), _ptr(dbg), int(dbg_stage)))
         return (raw, dbg) if want_dbg else raw
+
+    def limb_skip_stats(self, which, ray_batch, z, skts, cams=None):
+        """Measurement aid (pg_stage_eval, dbg_stage 97): what the limb masks of the fused kernel leave out on this launch --
+        the kernel itself counts.  Returns the fraction of (pass, limb) pairs left out of whole passes and the fraction of
+        (wave or column tile, limb) pairs left out at the finer level (which includes the former)."""
+        rb = _dev_f32(ray_batch, self.device)
+        zz = _dev_f32(z, self.device)
+        n, S = zz.shape
+        sk, ps = self._pose_args(skts, n)
+        cam = None if cams is None else _dev_f32(cams.reshape(-1), self.device)
+        raw = torch.empty(n, S, 4, device=self.device)
+        cnt = torch.zeros(64, device=self.device, dtype=torch.int32)
+        self._check(self.lib.pg_stage_eval(self.handle, self._stream(), int(which), n, S, _ptr(rb), _ptr(zz),
+                                           _ptr(sk), ps, _ptr(cam), _ptr(raw), cnt.data_ptr(), 97))
+        passes, per_pass, fine = (int(v) for v in cnt[:3].cpu())
+        per_fine = 48                                   # 8 waves / column tiles x 6 limbs per pass in both kernels
+        return {"passes": passes, "limbs_left_out_of_whole_passes_frac": per_pass / max(6 * passes, 1),
+                "limbs_left_out_frac": fine / max(per_fine * passes, 1)}
 
     def stage_composite(self, ray_batch, z, raw, n_importance=0):
         rb = _dev_f32(ray_batch, self.device)

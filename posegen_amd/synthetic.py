@@ -103,10 +103,11 @@ def make_bones(n_frames: int, seed: int = 1, sigma: float = 0.2) -> np.ndarray:
     return bones
 
 
-def make_pose(n_frames: int, seed: int = 1):
-    """bones, kps [F,24,3] f32, skts [F,24,4,4] f32 with the SURREAL rest pose."""
+def make_pose(n_frames: int, seed: int = 1, sigma: float = 0.2):
+    """bones, kps [F,24,3] f32, skts [F,24,4,4] f32 with the SURREAL rest pose; sigma = spread of the joint angles (0.2:
+    SURVEY.md 8(d); larger values fold the limbs towards the trunk)."""
     rest = smpl_rest_pose * SURREAL_REST_SCALE
-    bones = make_bones(n_frames, seed)
+    bones = make_bones(n_frames, seed, sigma)
     kps, skts, _ = bones_to_pose(bones, rest)
     return bones.astype(np.float32), kps.astype(np.float32), skts.astype(np.float32)
 

@@ -92,6 +92,7 @@ class _RenderRaysFn(torch.autograd.Function):
         # (a forward pass in between has overwritten the handle's one tape: the library refuses the stale id)
         r._check(r.lib.pg_train_backward(r.handle, r._stream(), ctx.tape_id, _ptr(a), _ptr(b), _ptr(c), _ptr(d), C.byref(structs[0]),
                                          C.byref(structs[1]) if ctx.n_nets > 1 else None))
+        caster._stale = True                            # (an optimiser step follows: the inference kernels' packed weights lag from here)
         return (None, None) + tuple(grads)
 
 
@@ -163,11 +164,21 @@ class TrainableRayCaster(torch.nn.Module):
     (trainer.py:265-266), `.module`, and `state_dict()` / `load_state_dict()` in the reference checkpoint layout
     (raycasters.py:752-788: `network_fn_state_dict` with `pts_linears.0.weight`, ..., `embed_state_dict`, ...), which
     `HipRayCaster.load_state_dict`, `load_raycaster` and the reference itself read back.
-    `sync_inference_weights()` hands the current values to the fused inference kernels (validation renders)."""
+    `sync_inference_weights()` hands the current values to the fused inference kernels (validation renders); a render
+    in eval mode does it by itself when a backward pass or a checkpoint load has changed the parameters since.
 
-    def __init__(self, caster: HipRayCaster):
+    `train_precision`: "fp32" (default: the reference trains in fp32, trainer.py:232-275; gradients within 1e-4 of its
+    autograd) or "bf16" (opt-in: the tape and the large GEMMs' operands in bf16, fp32 accumulate).  It is the TRAINING
+    step's arithmetic only and independent of the caster's rendering precision (`set_precision`)."""
+
+    def __init__(self, caster: HipRayCaster, train_precision: str = "fp32"):
         super().__init__()
+        if train_precision not in ("fp32", "bf16"):
+            raise ValueError(f"train_precision must be 'fp32' or 'bf16', not {train_precision!r}")
         self.caster = caster
+        self.train_precision = train_precision
+        caster.renderer.set_train_precision(train_precision)
+        self._stale = False                              # the inference kernels' packed weights lag the parameters
         self.cfg = caster.cfg
         dev = caster.renderer.device
         st = caster.renderer._state
@@ -237,11 +248,30 @@ class TrainableRayCaster(torch.nn.Module):
         self.caster.renderer.load_network(0, self.net_state_dict(0))
         if self.network_fine is not None:
             self.caster.renderer.load_network(1, self.net_state_dict(1))
+        self._stale = False
+
+    def _check_unused(self, unused):
+        """The reference's keywords the kernels do not honour are refused, in training and in eval mode alike."""
+        if not unused:
+            return
+        unused = dict(unused)
+        self.caster._check_preproc_kwargs(unused.pop("preproc_kwargs", None))
+        if unused.pop("nerf_type", "nerf") != "nerf" or not unused.pop("use_viewdirs", True):
+            raise NotImplementedError("only nerf_type='nerf' with view directions is on the HIP path")
+        if unused.get("network_fine") is not None and unused["network_fine"] is not self.network_fine:
+            raise NotImplementedError("a network_fine argument other than this caster's own fine network")
+        for k in ("retraw", "verbose", "ext_scale", "network_fine"):
+            unused.pop(k, None)
+        if unused:
+            raise TypeError(f"TrainableRayCaster.forward: unexpected keyword arguments {sorted(unused)}")
 
     def forward(self, ray_batch, N_samples=None, kp_batch=None, skts=None, cyls=None, bones=None, cams=None,
                 subject_idxs=None, lindisp=False, perturb=0., N_importance=0, raw_noise_std=0., ray_noise_std=0.,
                 pytest=False, draws: Optional[Dict[str, torch.Tensor]] = None, **unused):
+        self._check_unused(unused)
         if not (self.training and torch.is_grad_enabled()):
+            if self._stale:                              # a backward pass has run since the last packing: render what was trained
+                self.sync_inference_weights()
             return self.caster(ray_batch, N_samples=N_samples, kp_batch=kp_batch, skts=skts, cyls=cyls, bones=bones, cams=cams,
                                subject_idxs=subject_idxs, lindisp=lindisp, perturb=perturb, N_importance=N_importance,
                                raw_noise_std=raw_noise_std, ray_noise_std=ray_noise_std, pytest=pytest, draws=draws)
@@ -249,14 +279,6 @@ class TrainableRayCaster(torch.nn.Module):
             raise NotImplementedError("subject_idxs (multi-subject nets) are not supported")
         if skts is None or cyls is None:
             raise ValueError("skts and cyls are required (A-NeRF bone-relative rendering)")
-        if unused:
-            self.caster._check_preproc_kwargs(unused.pop("preproc_kwargs", None))
-            if unused.pop("nerf_type", "nerf") != "nerf" or not unused.pop("use_viewdirs", True):
-                raise NotImplementedError("only nerf_type='nerf' with view directions is on the HIP path")
-            for k in ("retraw", "verbose", "ext_scale", "network_fine"):
-                unused.pop(k, None)
-            if unused:
-                raise TypeError(f"TrainableRayCaster.forward: unexpected keyword arguments {sorted(unused)}")
         # The backward pass differentiates with respect to the networks' tensors only.  The reference's pose
         # optimisation (popt_layer, trainer.py:496-515) backpropagates into skts / kp through the embedding: refused
         # here rather than left without a gradient (out of scope).

@@ -20,13 +20,13 @@ def _loss_of(out, target):
     return loss
 
 
-def _trainable(g, precision="fp32"):
+def _trainable(g, train_precision="fp32", precision="fp32"):
     from posegen_amd.raycaster import HipRayCaster
     from posegen_amd.train import TrainableRayCaster
     cfg = cfg_from_golden(g)
     wc, wf, tv, td = model_for(cfg, int(g["seed_model"]))
     c = HipRayCaster.from_weights(cfg, wc, wf, float(g["tau_v"]), float(g["tau_d"]), device=DEV, precision=precision)
-    return cfg, TrainableRayCaster(c)
+    return cfg, TrainableRayCaster(c, train_precision=train_precision)
 
 
 @pytest.mark.parametrize("name", ["train_grads", "train_grads_h36m", "train_grads_softplus", "train_grads_raw"])
@@ -238,7 +238,7 @@ def test_bf16_training_mode_gradients_are_close_and_repeatable(name):
     parameter gradient within 1e-2, every sampled entry within 0.1 of its tensor's largest entry (bounds stated: bf16
     operands carry 8 bits; measured 5e-4 on the norms, 5e-2 on single entries), and bitwise the same on a second run."""
     g = load_golden(name)
-    cfg, m = _trainable(g, precision="bf16")
+    cfg, m = _trainable(g, train_precision="bf16")
     m.train()
     cams = torch.tensor(g["cams"]) if "cams" in g else None
     target = torch.tensor(g["target"], device=DEV)
@@ -265,4 +265,116 @@ def test_bf16_training_mode_gradients_are_close_and_repeatable(name):
     print(f"[{name}] bf16 training mode: worst relative gradient deviation {worst:.2e}")
     loss2, grads2 = run()
     assert loss2 == loss and all(torch.equal(grads[k], grads2[k]) for k in grads), "bitwise repeatable"
+    m.renderer.close()
+
+
+def test_training_precision_is_independent_of_the_rendering_precision():
+    """wrapping a caster that RENDERS in bf16 (every constructor's default) must not move the training step
+    off the reference's fp32 arithmetic: `TrainableRayCaster(caster)` trains in fp32 (gradients within 1e-4 of the
+    reference's autograd on the fixture) whatever `set_precision` says, before and after a render-side switch."""
+    g = load_golden("train_grads")
+    cfg, m = _trainable(g, precision="bf16")
+    assert m.train_precision == "fp32"
+    m.train()
+    for switch in (None, "fp16c"):
+        if switch:
+            m.renderer.set_precision(switch)
+        m.zero_grad()
+        out = m(torch.tensor(g["ray_batch"]), N_samples=cfg.n_samples, skts=torch.tensor(g["skts"]), cyls=torch.tensor(g["cyl"]),
+                N_importance=cfg.n_importance, draws=golden_draws(g))
+        loss = _loss_of(out, torch.tensor(g["target"], device=DEV))
+        assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+        loss.backward()
+        for tag, net in (("coarse", m.network), ("fine", m.network_fine)):
+            for k, p in net.named_parameters():
+                ref_vals, ref_norm = g[f"gval_{tag}_{k}"], float(g[f"gnorm_{tag}_{k}"])
+                got = p.grad.detach().cpu().numpy().reshape(-1)
+                scale = max(float(np.abs(ref_vals).max()), ref_norm / np.sqrt(got.size), 1e-12)
+                assert float(np.abs(got[grad_sample_index(got.size)] - ref_vals).max()) <= 1e-4 * scale + 1e-9, (switch, tag, k)
+    with pytest.raises(ValueError):
+        from posegen_amd.train import TrainableRayCaster
+        TrainableRayCaster(m.caster, train_precision="fp16")
+    m.renderer.close()
+
+
+def test_loss_curves_of_both_training_precisions_follow_the_oracle_autograd():
+    """more than single-step gradients.  24 Adam steps (lrate 5e-4, the reference's, raycasters.py:186-228) on one
+    batch with fixed draws, three ways: the oracle under torch autograd on the CPU (pinned to the reference's gradients),
+    the HIP step in fp32 and the HIP step on the bf16 tape.  The fp32 curve stays within 2e-4 (relative) of the oracle's at
+    every step, the bf16 curve within 2e-2, and all three fall."""
+    from oracle import anerf_oracle as orc
+    from posegen_amd import surreal_config
+    from posegen_amd.raycaster import HipRayCaster, make_training_draws
+    from posegen_amd.train import TrainableRayCaster
+    from tests.helpers import oracle_cfg
+    g = load_golden("train_grads")
+    cfg = surreal_config(n_samples=32, n_importance=8)
+    wc, wf, tv, td = model_for(cfg, 4)
+    n, steps = 48, 24
+    rb, sk, cy = torch.tensor(g["ray_batch"][:n]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    target = torch.tensor(g["target"][:n])
+    draws = make_training_draws(n, 32, 8, perturb=1., raw_noise_std=1., pytest=True)
+    # the oracle's curve
+    tw = lambda w: {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+    twc, twf = tw(wc), tw(wf)
+    opt = torch.optim.Adam(list(twc.values()) + list(twf.values()), lr=5e-4, betas=(0.9, 0.999))
+    ref_curve = []
+    for it in range(steps):
+        opt.zero_grad()
+        loss = _loss_of(orc.render_rays(rb, sk, cy, oracle_cfg(cfg, tv, td), twc, twf, 32, 8, draws=draws), target)
+        loss.backward()
+        opt.step()
+        ref_curve.append(float(loss.detach()))
+    curves = {}
+    for tp in ("fp32", "bf16"):
+        c = HipRayCaster.from_weights(cfg, wc, wf, float(tv), float(td), device=DEV, precision="bf16")
+        m = TrainableRayCaster(c, train_precision=tp)
+        m.train()
+        o = torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        cur = []
+        for it in range(steps):
+            o.zero_grad()
+            out = m(rb, N_samples=32, skts=sk, cyls=cy, N_importance=8, draws={k: v.to(DEV) for k, v in draws.items()})
+            loss = _loss_of(out, target.to(DEV))
+            loss.backward()
+            o.step()
+            cur.append(float(loss.detach()))
+        curves[tp] = cur
+        m.renderer.close()
+    dev32 = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(curves["fp32"], ref_curve))
+    dev16 = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(curves["bf16"], ref_curve))
+    print(f"loss {ref_curve[0]:.5f} -> {ref_curve[-1]:.5f} (oracle); worst relative deviation of the curve: fp32 {dev32:.2e}, bf16 {dev16:.2e}")
+    assert ref_curve[-1] < ref_curve[0] and curves["fp32"][-1] < curves["fp32"][0] and curves["bf16"][-1] < curves["bf16"][0]
+    assert dev32 <= 2e-4, dev32
+    assert dev16 <= 2e-2, dev16
+
+
+def test_eval_render_after_a_step_uses_the_trained_weights_and_refuses_unknown_keywords():
+    """the eval / no-grad branch.  After a backward pass the inference kernels' packed weights lag the parameters:
+    an eval-mode render packs them first (no explicit sync_inference_weights()), so it equals the training-mode forward
+    without noise; and it refuses the keywords the kernels do not honour exactly as the training branch does."""
+    g = load_golden("train_grads")
+    cfg, m = _trainable(g)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3, betas=(0.9, 0.999))
+    rb, sk, cy = torch.tensor(g["ray_batch"]), torch.tensor(g["skts"]), torch.tensor(g["cyl"])
+    target = torch.tensor(g["target"], device=DEV)
+    for it in range(3):
+        opt.zero_grad()
+        out = m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+        _loss_of(out, target).backward()
+        opt.step()
+    assert m._stale
+    m.eval()
+    with torch.no_grad():
+        ev = m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+        with pytest.raises(TypeError):
+            m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance, no_such_argument=1)
+        with pytest.raises(NotImplementedError):
+            m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance, nerf_type="mipnerf")
+    assert not m._stale
+    m.train()
+    tr = m(rb, N_samples=cfg.n_samples, skts=sk, cyls=cy, N_importance=cfg.n_importance)
+    for k in ("rgb_map", "acc_map"):
+        assert float((ev[k] - tr[k].detach()).abs().max()) <= 1e-4, k
     m.renderer.close()
