@@ -306,6 +306,24 @@ __device__ __forceinline__ void split_span(f32x4 (&acc)[2][TT::NCT], WPair (&W)[
 __device__ __forceinline__ void zero4(unsigned (&z)[4]) {
     asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z[0]), "=v"(z[1]), "=v"(z[2]), "=v"(z[3]));
 }
+// the two halves of conv_write: the fragments formed in registers (VALU only) / stored
+struct HFrags { unsigned h[TT::NCT][4], x[TT::NCT][4]; };
+template <bool RELU>
+__device__ __forceinline__ void conv_form(const f32x4 (&acc)[2][TT::NCT], HFrags& f, float s129) {
+    static_for<0, TT::NCT>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        const float v[8] = {acc[0][c][0], acc[0][c][1], acc[0][c][2], acc[0][c][3], acc[1][c][0], acc[1][c][1], acc[1][c][2], acc[1][c][3]};
+        conv4<RELU>(v, f.h[c], f.x[c], s129);
+    });
+}
+__device__ __forceinline__ void conv_store(const HFrags& f, uint8_t* hw) {
+    static_for<0, TT::NCT>([&](auto ic) {
+        constexpr int c = decltype(ic)::value;
+        st128(hw + c * 2048, f.h[c]);
+        st128(hw + c * 2048 + 1024, f.x[c]);
+    });
+}
+
 // pins the order: every load named here has been issued (and, as far as hipcc knows, consumed) before anything behind it
 __device__ __forceinline__ void pin4(a128& a, a128& b, a128& c, a128& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 
@@ -399,6 +417,9 @@ __global__ __launch_bounds__(NTHR2, 2) void evalc2_kernel(const EvalArgs a) {
     // summed over the launch into a.dbg[0..2] (unsigned)
     const bool count_skips = a.dbg != nullptr && a.dbg_stage == 97;
     unsigned n_cnt[3] = {0u, 0u, 0u};
+#if defined(PG_C2_YOUNG_PRIO)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(PG_C2_YOUNG_PRIO);       // (experiment: the second-dispatched half loses every issue arbitration)
+#endif
     // per-wave constants of the pass loop
     const uint8_t* wx_wave = wbase + wave * TT::KBLK;       // + section + k-unit * NW * KBLK
     WPair W[4];
@@ -682,10 +703,23 @@ __global__ __launch_bounds__(NTHR2, 2) void evalc2_kernel(const EvalArgs a) {
         for (int hs = 0; hs < 7; ++hs) {
             const uint8_t* wl = wx_p + TT::OFF_HID(0) + hs * TT::SEC_H + (hs >= 5 ? TT::SEC_X : 0);
             issue_a(A[0], lane16, wl);
+#if defined(PG_C2_EARLY_CONV)
+            // The first-dispatched wave of a SIMD wins the MFMA arbitration, is through a layer's MFMAs ~40 % earlier than its
+            // partner and then waits at this barrier (profiles/r5_c2_plain_stamps.txt: 22 k ticks per pass): it forms its
+            // fragments (VALU only, no LDS) in that time, beside the partner's MFMAs; the partner converts behind the barrier.
+            HFrags hf;
+            settle<0, TT::NCT>(acc);
+            if (wave < 4) conv_form<true>(acc, hf, s129);
+            lds_barrier();                                              // everyone is done reading the previous input
+            C2_STAMP(3);
+            if (wave >= 4) conv_form<true>(acc, hf, s129);
+            conv_store(hf, hw);
+#else
             lds_barrier();                                              // everyone is done reading the previous input
             C2_STAMP(3);
             settle<0, TT::NCT>(acc);
             conv_write<true>(acc, hw, s129);
+#endif
             {
                 const f32x4 b0 = bias_tile(bias, BS_LAYER0 + (hs + 1) * NT16 + 2 * wave, g_p);
                 const f32x4 b1 = bias_tile(bias, BS_LAYER0 + (hs + 1) * NT16 + 2 * wave + 1, g_p);
