@@ -214,9 +214,10 @@ int ensure_stream_ro(pg_handle* h, int which, int prec) {
 }
 
 // ... which runs when the launch has one pose and no frame codes (POSEGEN_ONCHIP=0 forces the record variant: A/B, tests)
-bool use_onchip(bool fc, long long pose_stride) {
+// (pg_evalc.hip's on-chip form needs one pose per launch: `shared_pose_only`; the 16x16x32 kernel's reads per-ray poses too)
+bool use_onchip(bool fc, long long pose_stride, bool shared_pose_only = false) {
     static const bool allowed = [] { const char* e = std::getenv("POSEGEN_ONCHIP"); return !(e && e[0] == '0'); }();
-    return allowed && !fc && pose_stride == 0;
+    return allowed && !fc && (pose_stride == 0 || !shared_pose_only);
 }
 
 int ensure_stream_cr(pg_handle* h, int which) {
@@ -347,10 +348,10 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
     const bool fc = h->cfg.framecode_ch > 0;
-    const bool onchip = sa && fact && (!dbg || dbg_stage == 97) && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
+    const bool onchip = sa && fact && (!dbg || (dbg_stage == 97 && pose_stride == 0)) && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
     const bool c2 = compk && (!dbg || dbg_stage == 99 || dbg_stage == 97) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
-    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
+    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride, true);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
     const bool crec = !c2 && compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec) : c2 ? ensure_c2(h, which)
            : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);

@@ -343,8 +343,11 @@ __device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds,
 // LDS), and the view layer's direction part Y by y_segment16 from limb chunks of the weight stream.
 // CNT (measurement aid, dbg_stage 97; its own instantiation): passes, limbs left out of whole passes (of 6 per pass) and
 // limbs left out per wave (of 48 per pass), summed over the launch into a.dbg[0..2] (unsigned)
-template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false>
+// PP (on-chip variant only): per-ray poses (a.pose_stride != 0, as the reference's batchify_rays hands them over,
+// core/trainer.py:64-81) -- the bone rows of a pass's rays are read from a.skts instead of the LDS copy of the one pose
+template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false, bool PP = false>
 __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
+    static_assert(!PP || OC, "per-ray poses without records are a form of the on-chip variant");
     static_assert(!(OC && FC), "the on-chip variant has no frame-code pseudo joint");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDSR_BIAS);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         cut[tid] = far * far;
     }
     if (OC) {       // the pose's bone rows by joint slot; an all-zero Y image (limbs no pass has computed yet)
-        for (int i = tid; i < J * 12; i += NTHR) reinterpret_cast<float*>(smem + LDSR_SK)[i] = a.skts[slot_joint_dev(i / 12) * 16 + i % 12];
+        if (!PP) for (int i = tid; i < J * 12; i += NTHR) reinterpret_cast<float*>(smem + LDSR_SK)[i] = a.skts[slot_joint_dev(i / 12) * 16 + i % 12];
         for (int i = tid; i < MAXR_F * REC_Y_BYTES / 16; i += NTHR) reinterpret_cast<uint4*>(smem + LDSR_Y)[i] = make_uint4(0u, 0u, 0u, 0u);
     }
 #if defined(PG_YOUNG_PRIO)
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         if (tid < MAXR_F * J) {
             const int k = tid / J, sl = tid - k * J;
             const long long ray = min((long long)r0 + k, (long long)a.n_rays - 1);
-            ab_row(sk_lds + sl * 12, a.rays + ray * 11, a.z[ray * a.S], a.z[ray * a.S + a.S - 1],
+            const float* skr = PP ? a.skts + ray * a.pose_stride + slot_joint_dev(sl) * 16 : sk_lds + sl * 12;
+            ab_row(skr, a.rays + ray * 11, a.z[ray * a.S], a.z[ray * a.S + a.S - 1],
                    reinterpret_cast<float4*>(smem + LDSR_AB + k * REC_AB_BYTES + sl * 32));
         }
     } else if ((int)blockIdx.x < a.n_iters && wave < LDS_AB_BYTES / 1024)
@@ -549,7 +553,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             const int item = wave * 15 + (lane_p & 15);         // (per pass: addresses derived from it are not hoisted out of the pass loop)
             if (lane_p < 15) {
                 const int k = item / J, sl = item - k * J;
-                ab_row(sk_lds + sl * 12, stage + 11 * k, stage[64 + 2 * k], stage[64 + 2 * k + 1],
+                const float* skr = PP ? a.skts + min((long long)r0n + k, (long long)a.n_rays - 1) * a.pose_stride + slot_joint_dev(sl) * 16 : sk_lds + sl * 12;
+                ab_row(skr, stage + 11 * k, stage[64 + 2 * k], stage[64 + 2 * k + 1],
                        reinterpret_cast<float4*>(smem + LDSR_AB + (abuf ^ 1) * LDS_AB_BYTES + k * REC_AB_BYTES + sl * 32));
             }
         }
@@ -674,9 +679,9 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     st.drain();
 }
 
-template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false>
+template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false, bool PP = false>
 static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream) {
-    auto k = eval16r_kernel<V, FC, TAPS, OC, CNT>;
+    auto k = eval16r_kernel<V, FC, TAPS, OC, CNT, PP>;
     constexpr int lds = OC ? LDSR_TOTAL_OC : LDSR_TOTAL;
     static std::atomic<unsigned long long> attr_done{0};       // per device (pg_device.h)
     const hipError_t ae = ensure_lds_attr(reinterpret_cast<const void*>(k), lds, attr_done);
@@ -687,6 +692,7 @@ static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream
 
 template <typename V>
 static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip, int grid, hipStream_t s) {
+    if (onchip && a.pose_stride != 0) return (a.dbg && a.dbg_stage != 99) ? hipErrorInvalidValue : launch_eval16r<V, false, false, true, false, true>(a, grid, s);
     if (onchip && a.dbg && a.dbg_stage == 97) return launch_eval16r<V, false, false, true, true>(a, grid, s);      // the limb-mask counters
     const bool taps = a.dbg && a.dbg_stage != 99;
     if (onchip) return taps ? hipErrorInvalidValue : launch_eval16r<V, false, false, true>(a, grid, s);     // (no debug taps in this variant)
@@ -698,10 +704,10 @@ static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip,
 
 // needs S >= pgl::FACT_MIN_S, the 16-row bias table (pack_bias_s) and
 //   onchip = 0: the R weight stream (pack_stream_r) and the per-ray records of pg_rayrec.hip in a.rec_ab / a.rec_y
-//   onchip = 1: the on-chip R stream (pack_stream_r(..., onchip)), one pose for all rays (a.pose_stride == 0), no frame codes
+//   onchip = 1: the on-chip R stream (pack_stream_r(..., onchip)), no frame codes; one pose for all rays or (a.pose_stride != 0) a pose per ray
 extern "C" int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int onchip, int grid, void* stream) {
     using namespace pgd;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (onchip && (framecode || a->pose_stride != 0)) return (int)hipErrorInvalidValue;
+    if (onchip && framecode) return (int)hipErrorInvalidValue;
     return (int)(fp16 ? dispatch_eval16r<f16x8>(*a, framecode, onchip, grid, s) : dispatch_eval16r<bf16x8>(*a, framecode, onchip, grid, s));
 }
