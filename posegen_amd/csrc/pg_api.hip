@@ -190,7 +190,7 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     return PG_OK;
 }
 
-// the on-chip variant of the 16x16x32 kernel (one pose per launch, no frame codes): its stream; the bias table is shared
+// the on-chip variant of the 16x16x32 kernel (no per-ray records): its stream; the bias table is shared
 int ensure_stream_ro(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
@@ -213,11 +213,40 @@ int ensure_stream_ro(pg_handle* h, int which, int prec) {
     return PG_OK;
 }
 
-// ... which runs when the launch has one pose and no frame codes (POSEGEN_ONCHIP=0 forces the record variant: A/B, tests)
-// (pg_evalc.hip's on-chip form needs one pose per launch: `shared_pose_only`; the 16x16x32 kernel's reads per-ray poses too)
-bool use_onchip(bool fc, long long pose_stride, bool shared_pose_only = false) {
-    static const bool allowed = [] { const char* e = std::getenv("POSEGEN_ONCHIP"); return !(e && e[0] == '0'); }();
-    return allowed && !fc && (pose_stride == 0 || !shared_pose_only);
+// ... which runs for rays of at most ONCHIP_MAX_S samples.  The 16x16x32 kernel's on-chip variant takes per-ray poses and
+// frame codes too; pg_evalc.hip's on-chip form needs one pose per launch and no frame codes (`plain_only`) and has no
+// sample-count rule.  The on-chip variant forms a ray's rows in every pass the ray has points in, the record variant once
+// per ray in a kernel in front: measured on one box (profiles/r5_ab_onchip_by_samples.txt, bf16 512 x 512 frames) the two
+// tie at 64 + 16 samples (31.7 / 31.8 ms), on-chip wins at 96 + 16 (43.3 / 43.6) and records win from 128 + 16 on (59.3 /
+// 58.0; with frame codes 59.7 / 58.2) -- at a cost of 8.75 KiB of HBM per ray.  POSEGEN_ONCHIP=0 forces the record
+// variants, POSEGEN_ONCHIP=2 the on-chip ones whatever the sample count (A/B, tests).
+constexpr int ONCHIP_MAX_S = 112;
+bool use_onchip(bool fc, long long pose_stride, int S, bool plain_only = false) {
+    static const int mode = [] { const char* e = std::getenv("POSEGEN_ONCHIP"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }();
+    if (plain_only) return mode != 0 && !fc && pose_stride == 0;
+    return mode == 2 || (mode == 1 && S <= ONCHIP_MAX_S);
+}
+
+// The frame code's part of the view layer for every code (and the mean row, embedding.py:25-26), as the on-chip variant reads it:
+// Yc[c][o] = sum_k W_view[o][256 + 648 + k] codes[c][k] in fp32 (sums in double) -- 16 products per value once per
+// pg_set_framecodes / pg_load_weights instead of once per ray.
+int ensure_ycode(pg_handle* h, int which) {
+    NetState& ns = h->net[which];
+    if (ns.d_ycode) return PG_OK;
+    if (!ns.loaded || ns.codes_host.empty()) return pg_fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
+    const int vcols = W + CH_D + FC_CH;
+    const std::vector<float>& wv = ns.host[20];
+    std::vector<float> yc((size_t)(ns.n_codes + 1) * VW);
+    for (int c = 0; c <= ns.n_codes; ++c)
+        for (int o = 0; o < VW; ++o) {
+            double s = 0.0;
+            for (int k = 0; k < FC_CH; ++k) s += (double)wv[(size_t)o * vcols + W + CH_D + k] * (double)ns.codes_host[(size_t)c * FC_CH + k];
+            yc[(size_t)c * VW + o] = (float)s;
+        }
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_ycode), yc.size() * sizeof(float)));
+    PG_HIP(h, hipMemcpy(ns.d_ycode, yc.data(), yc.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PG_OK;
 }
 
 int ensure_stream_cr(pg_handle* h, int which) {
@@ -307,9 +336,9 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
     auto one = [&](int prec) {
         const bool fc = h->cfg.framecode_ch > 0;
-        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
+        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(fc, 0, FACT_MIN_S) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
         if (prec == PG_PREC_FP16C && use_evalc2(FACT_MIN_S)) return ensure_c2(h, which);
-        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(fc, 0) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
+        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(fc, 0, FACT_MIN_S, true) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
     };
     if (mode != PG_PREC_FP16M) return one(mode);
@@ -348,14 +377,15 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
     const bool fc = h->cfg.framecode_ch > 0;
-    const bool onchip = sa && fact && (!dbg || (dbg_stage == 97 && pose_stride == 0)) && use_onchip(fc, pose_stride);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
+    const bool onchip = sa && fact && (!dbg || (dbg_stage == 97 && pose_stride == 0 && !fc)) && use_onchip(fc, pose_stride, S);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
     const bool c2 = compk && (!dbg || dbg_stage == 99 || dbg_stage == 97) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
-    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride, true);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
+    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride, S, true);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
     const bool crec = !c2 && compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec) : c2 ? ensure_c2(h, which)
            : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
     if (rc) return rc;
+    if (onchip && fc && (rc = ensure_ycode(h, which))) return rc;
     const int y_bytes = crec ? RECC_Y_BYTES : REC_Y_BYTES;
     if ((recs || crec) && (rc = ensure_rec(h, n, y_bytes))) return rc;
     NetState& ns = h->net[which];
@@ -365,7 +395,7 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     a.codes = fc ? ns.d_codes : nullptr;
     a.wstream = onchip ? ns.d_stream_ro[prec] : recs ? ns.d_stream_r[prec] : c2 ? ns.d_c2 : conchip ? ns.d_stream_co : crec ? ns.d_stream_cr
               : ns.d_stream[prec][fact];
-    a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : nullptr;
+    a.wy = recs ? ns.d_vy[prec] : crec ? reinterpret_cast<const uint8_t*>(ns.d_vyc) : (onchip && fc) ? reinterpret_cast<const uint8_t*>(ns.d_ycode) : nullptr;
     a.bias = (recs || onchip || c2) ? ns.d_bias_s : ns.d_bias;
     if (recs || crec) {
         a.rec_y = h->rec;
@@ -587,6 +617,7 @@ void pg_destroy(pg_handle* h) {
         for (auto& pp : ns.d_stream) for (auto& p : pp) if (p) (void)hipFree(p);
         for (auto& p : ns.d_vy) if (p) (void)hipFree(p);
         if (ns.d_bias_s) (void)hipFree(ns.d_bias_s);
+        if (ns.d_ycode) (void)hipFree(ns.d_ycode);
         if (ns.d_stream_cr) (void)hipFree(ns.d_stream_cr);
         if (ns.d_stream_co) (void)hipFree(ns.d_stream_co);
         if (ns.d_c2) (void)hipFree(ns.d_c2);
@@ -638,6 +669,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
         if (ns.d_stream_ro[p]) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_ro[p])); ns.d_stream_ro[p] = nullptr; }
     }
     if (ns.d_bias_s) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_bias_s)); ns.d_bias_s = nullptr; }
+    if (ns.d_ycode) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_ycode)); ns.d_ycode = nullptr; }
     if (ns.d_stream_cr) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_cr)); ns.d_stream_cr = nullptr; }
     if (ns.d_stream_co) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_stream_co)); ns.d_stream_co = nullptr; }
     if (ns.d_c2) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_c2)); ns.d_c2 = nullptr; }
@@ -686,6 +718,7 @@ int pg_set_framecodes(pg_handle* h, int which, const float* codes, int n_codes) 
     ns.n_codes = n_codes;
     PG_HIP(h, hipSetDevice(h->device));
     if (ns.d_codes) { PG_HIP(h, hipDeviceSynchronize()); PG_HIP(h, hipFree(ns.d_codes)); ns.d_codes = nullptr; }
+    if (ns.d_ycode) { PG_HIP(h, hipFree(ns.d_ycode)); ns.d_ycode = nullptr; }
     PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_codes), ns.codes_host.size() * sizeof(float)));
     PG_HIP(h, hipMemcpy(ns.d_codes, ns.codes_host.data(), ns.codes_host.size() * sizeof(float), hipMemcpyHostToDevice));
     PG_FORWARD(h, pg_set_framecodes(hh, which, codes, n_codes));
@@ -894,7 +927,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     const bool fact = use_fact(precision, FACT_MIN_S);
     const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
     if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
-        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0, FACT_MIN_S) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
         return PG_OK;
     }
@@ -904,7 +937,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
         return PG_OK;
     }
     if (compk && use_comp_rec(FACT_MIN_S)) {     // record variant of the compensated kernel (the usual case)
-        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0) ? pgp::C::NCHUNK_OC : pgp::C::NCHUNK_R) * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0, FACT_MIN_S, true) ? pgp::C::NCHUNK_OC : pgp::C::NCHUNK_R) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::C::MFMA_PER_GROUP_R;
         return PG_OK;
     }

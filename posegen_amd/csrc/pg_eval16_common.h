@@ -368,8 +368,10 @@ __device__ __forceinline__ void dump_frags(const EvalArgs& a, int stage, long lo
 
 // ---- on-chip variants of the record kernels: the per-ray rows are formed by the workgroup itself ----
 // 64 dwords by LDS-DMA with a per-lane source offset (bytes from a wave-uniform base) to LDS dst + 4 lane
+// (s_nop 4: the base may sit in SGPRs a v_readlane / v_readfirstlane has just written -- a spill reload, a wave-uniform index --
+// and VMEM reading such an SGPR needs 5 wait states, which hipcc does not insert in front of inline asm)
 __device__ __forceinline__ void dma_dwords(const void* base, uint32_t lane_off, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
 }
 
 // One (ray, joint slot) record row of the on-chip variants (pg_eval16r.hip OC, pg_evalc.hip OC) -- what pg_rayrec.hip writes to HBM for the record variant:

@@ -74,10 +74,14 @@ static_assert(LDSR_BIAS % 16 == 0 && LDSR_CUT % 16 == 0 && LDSR_AB % 16 == 0 && 
 static_assert(LDSR_TOTAL <= 160 * 1024, "LDS budget of one CU");
 // on-chip variant: + the pose's bone rows by joint slot (24 x 12 floats) and a staging area for the next pass's rays
 // (64 floats of ray_batch rows, 64 floats of first / last depths)
+// with frame codes: + 64 floats (one DMA of a wave; 5 used) of the next pass's frame-code indices in the staging area, and the code's part of the view
+// layer Yc[code][128 out] (fp32 rows of a host-made table) of this pass's / the next pass's rays
 constexpr int LDSR_SK = LDSR_TOTAL;
 constexpr int LDSR_STAGE = LDSR_SK + J * 12 * 4;
-constexpr int LDSR_TOTAL_OC = LDSR_STAGE + 512;
-static_assert(LDSR_SK % 16 == 0 && LDSR_STAGE % 16 == 0 && LDSR_TOTAL_OC <= 160 * 1024, "LDS budget of one CU (on-chip variant)");
+constexpr int LDSR_YC = LDSR_STAGE + 768;
+constexpr int LDSR_YC_BYTES = MAXR_F * VW * 4;
+constexpr int LDSR_TOTAL_OC = LDSR_YC + 2 * LDSR_YC_BYTES;
+static_assert(LDSR_SK % 16 == 0 && LDSR_STAGE % 16 == 0 && LDSR_YC % 16 == 0 && LDSR_TOTAL_OC <= 160 * 1024, "LDS budget of one CU (on-chip variant)");
 
 __device__ __forceinline__ f32x4 load_bias16(const float* bias, int tile, int g) {
     const float4 b = *reinterpret_cast<const float4*>(bias + tile * 16 + 4 * g);
@@ -177,6 +181,17 @@ __device__ __forceinline__ void x_segment16(f32x4 (*acc)[2], ST& st, const float
 // cos e, .., sin 8 e, cos 8 e) per component (encoders.py:172-193, cutoff_embedder.py:45-46), hardware sin / cos.
 // Limbs out of range of the whole pass keep whatever an earlier pass left (zeros at first): the second stage multiplies
 // them by exactly zero.
+// the frame code's part of the view layer of the pass's rays: Yc rows (fp32, staged in LDS) -> element 6 of lane group 0 of
+// the Y image's A fragments (vy16_slot_joint: the pseudo joint JC), every thread of the workgroup two values per ray pair
+template <typename V>
+__device__ __forceinline__ void y_code16(const float* yc, uint8_t* ylds, int nrm1, int tid) {
+    using E = typename Op<V>::E;
+    for (int idx = tid; idx < (nrm1 + 1) * VW; idx += NTHR) {
+        const int ray = idx / VW, o = idx - ray * VW;
+        *reinterpret_cast<E*>(ylds + ray * REC_Y_BYTES + (o >> 4) * 1024 + (o & 15) * 16 + 2 * JG) = (E)yc[idx];
+    }
+}
+
 template <typename V, typename ST>
 __device__ __forceinline__ void y_segment16(ST& st, int gmask, const uint8_t* ab, uint8_t* ylds, int nrm1, int wave, int lane) {
     using E = typename Op<V>::E;
@@ -337,8 +352,10 @@ __device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds,
 
 // TAPS = the debug tap of pg_stage_eval (stage 0: pre-activation of density layer 0) compiled in: its own
 // instantiation, launched only when a dump is asked for
-// OC = the on-chip variant (one pose shared by the launch's rays, no frame codes -- BASELINE config 2): no per-ray
-// records in HBM and no record kernel in front.  The (a, b) rows of a pass's rays are formed by the workgroup a pass
+// OC = the on-chip variant: no per-ray records in HBM and no record kernel in front.  With frame codes (FC; BASELINE config
+// 4) the code's part of the view layer is a row of a table made on the host when codes or weights change (a.wy:
+// Yc[code][128] = W_view[:, 904:920] codes[code], fp32), staged into LDS a pass ahead and copied into the pseudo-joint
+// slot of the Y image.  The (a, b) rows of a pass's rays are formed by the workgroup a pass
 // ahead from the rays themselves (LDS-DMA of their ray_batch rows and first / last depths, the pose's bone rows kept in
 // LDS), and the view layer's direction part Y by y_segment16 from limb chunks of the weight stream.
 // CNT (measurement aid, dbg_stage 97; its own instantiation): passes, limbs left out of whole passes (of 6 per pass) and
@@ -348,7 +365,6 @@ __device__ __forceinline__ void y_apply16(f32x4 (*vacc)[2], const uint8_t* ylds,
 template <typename V, bool FC, bool TAPS, bool OC, bool CNT = false, bool PP = false>
 __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
     static_assert(!PP || OC, "per-ray poses without records are a form of the on-chip variant");
-    static_assert(!(OC && FC), "the on-chip variant has no frame-code pseudo joint");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* bias = reinterpret_cast<float*>(smem + LDSR_BIAS);
     float* cut = reinterpret_cast<float*>(smem + LDSR_CUT);
@@ -402,6 +418,15 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         }
     } else if ((int)blockIdx.x < a.n_iters && wave < LDS_AB_BYTES / 1024)
         dma_piece(rec_ab + (long long)r0 * REC_AB_BYTES + wave * 1024, lds0 + LDSR_AB + wave * 1024, lane16);
+    if (OC && FC) {     // the code rows of the first pass's rays
+        const float* ytab = reinterpret_cast<const float*>(a.wy);
+        for (int idx = tid; idx < MAXR_F * VW; idx += NTHR) {
+            const int k = idx / VW, o = idx - k * VW;
+            const float cf = a.cams ? a.cams[min((long long)r0 + k, (long long)a.n_rays - 1)] : -1.0f;
+            const int ci = cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1);
+            reinterpret_cast<float*>(smem + LDSR_YC)[idx] = ytab[(long long)ci * VW + o];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     int abuf = 0;
@@ -497,7 +522,8 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
                 else if (wave == 1) {
                     const long long ray = min(rn + min(lane_p >> 1, MAXR_F - 1), (long long)a.n_rays - 1);
                     dma_dwords(a.z, (uint32_t)((ray * a.S + ((lane_p & 1) ? a.S - 1 : 0)) * 4), lds0 + LDSR_STAGE + 256);
-                }
+                } else if (FC && wave == 2 && a.cams)         // their frame-code indices
+                    dma_dwords(a.cams, (uint32_t)(min(rn + min(lane_p, MAXR_F - 1), (long long)a.n_rays - 1) * 4), lds0 + LDSR_STAGE + 512);
                 return;
             }
             const uint8_t* ysrc = a.rec_y + (size_t)r0 * REC_Y_BYTES + wave * 1024;
@@ -541,6 +567,7 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
         if constexpr (OC) {
             // the view layer's direction part of this pass's rays, for the limbs in range
             y_segment16<V>(st, gmask, smem + LDSR_AB + abuf * LDS_AB_BYTES, smem + LDSR_Y, nrm1, wave, lane_p);
+            if (FC) y_code16<V>(reinterpret_cast<const float*>(smem + LDSR_YC + abuf * LDSR_YC_BYTES), smem + LDSR_Y, nrm1, wave * 64 + lane_p);
         }
         PG_STAMP(2);
         // ---- layers 1..4 ----
@@ -550,6 +577,13 @@ __global__ __launch_bounds__(NTHR, 2) void eval16r_kernel(const EvalArgs a) {
             // between that chunk's refill pieces: the counted wait of the SECOND entry behind it covers it, and that
             // entry's barrier makes the other wave's share visible -- layer 1's four entries lie in between.  15 of each
             // wave's lanes take one (ray, joint slot) each.
+            if (FC && wave < MAXR_F) {      // the NEXT pass's code rows: ray `wave`, two dword DMAs of 64 floats each (landed entries before the pass ends)
+                const float cf = a.cams ? stage[128 + wave] : -1.0f;
+                const int ci = __builtin_amdgcn_readfirstlane(cf < 0.0f ? a.n_codes : min((int)cf, a.n_codes - 1));
+                const uint32_t dst = lds0 + LDSR_YC + (abuf ^ 1) * LDSR_YC_BYTES + wave * (VW * 4);
+                dma_dwords(a.wy, (uint32_t)((ci * VW + lane_p) * 4), dst);
+                dma_dwords(a.wy, (uint32_t)((ci * VW + 64 + lane_p) * 4), dst + 256);
+            }
             const int item = wave * 15 + (lane_p & 15);         // (per pass: addresses derived from it are not hoisted out of the pass loop)
             if (lane_p < 15) {
                 const int k = item / J, sl = item - k * J;
@@ -692,10 +726,14 @@ static hipError_t launch_eval16r(const EvalArgs& a, int grid, hipStream_t stream
 
 template <typename V>
 static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip, int grid, hipStream_t s) {
-    if (onchip && a.pose_stride != 0) return (a.dbg && a.dbg_stage != 99) ? hipErrorInvalidValue : launch_eval16r<V, false, false, true, false, true>(a, grid, s);
-    if (onchip && a.dbg && a.dbg_stage == 97) return launch_eval16r<V, false, false, true, true>(a, grid, s);      // the limb-mask counters
+    if (onchip) {       // (no debug taps in this variant; 99: the stamps of a PG_STAMPS build, 97: the limb-mask counters)
+        if (a.dbg && a.dbg_stage != 99 && a.dbg_stage != 97) return hipErrorInvalidValue;
+        const bool pp = a.pose_stride != 0;
+        if (a.dbg && a.dbg_stage == 97) return (pp || framecode) ? hipErrorInvalidValue : launch_eval16r<V, false, false, true, true>(a, grid, s);
+        if (framecode) return pp ? launch_eval16r<V, true, false, true, false, true>(a, grid, s) : launch_eval16r<V, true, false, true>(a, grid, s);
+        return pp ? launch_eval16r<V, false, false, true, false, true>(a, grid, s) : launch_eval16r<V, false, false, true>(a, grid, s);
+    }
     const bool taps = a.dbg && a.dbg_stage != 99;
-    if (onchip) return taps ? hipErrorInvalidValue : launch_eval16r<V, false, false, true>(a, grid, s);     // (no debug taps in this variant)
     if (taps) return framecode ? launch_eval16r<V, true, true, false>(a, grid, s) : launch_eval16r<V, false, true, false>(a, grid, s);
     return framecode ? launch_eval16r<V, true, false, false>(a, grid, s) : launch_eval16r<V, false, false, false>(a, grid, s);
 }
@@ -704,10 +742,11 @@ static hipError_t dispatch_eval16r(const EvalArgs& a, int framecode, int onchip,
 
 // needs S >= pgl::FACT_MIN_S, the 16-row bias table (pack_bias_s) and
 //   onchip = 0: the R weight stream (pack_stream_r) and the per-ray records of pg_rayrec.hip in a.rec_ab / a.rec_y
-//   onchip = 1: the on-chip R stream (pack_stream_r(..., onchip)), no frame codes; one pose for all rays or (a.pose_stride != 0) a pose per ray
+//   onchip = 1: the on-chip R stream (pack_stream_r(..., onchip)); one pose for all rays or (a.pose_stride != 0) a pose per ray; with
+//               frame codes a.wy = the table Yc[n_codes + 1][128] floats (W_view[:, 904:920] codes[c]) and a.cams the per-ray indices
 extern "C" int pg_launch_eval16r(const pgd::EvalArgs* a, int fp16, int framecode, int onchip, int grid, void* stream) {
     using namespace pgd;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (onchip && framecode) return (int)hipErrorInvalidValue;
+    if (onchip && framecode && !a->wy) return (int)hipErrorInvalidValue;       // (the code table Yc: pg_api.hip ensure_ycode)
     return (int)(fp16 ? dispatch_eval16r<f16x8>(*a, framecode, onchip, grid, s) : dispatch_eval16r<bf16x8>(*a, framecode, onchip, grid, s));
 }

@@ -20,6 +20,7 @@ struct NetState {
     uint8_t* d_stream_ro[PG_PREC_COUNT] = {};     // 16x16x32 kernel, on-chip variant (no per-ray records): stream
     uint8_t* d_stream_r[PG_PREC_COUNT] = {};      // 16x16x32 kernel with per-ray records (pg_eval16r.hip): stream,
     float* d_bias_s = nullptr;                    // ... and its 16-row bias table
+    float* d_ycode = nullptr;                     // on-chip variant with frame codes: Yc[n_codes + 1][128] = W_view[:, 904:920] codes[c] (ensure_ycode)
     uint8_t* d_c2 = nullptr;                      // compensated-fp16 kernel with the out tiles over the waves (pg_evalc2.hip): weights (pg_program.h T)
     uint8_t* d_stream_co = nullptr;               // compensated-fp16 kernel, on-chip form of the record variant (pg_evalc.hip OC): stream
     uint8_t* d_stream_cr = nullptr;               // compensated-fp16 kernel, record variant (pg_evalc.hip REC): stream,

@@ -29,7 +29,8 @@ def test_config4_h36m_full_frame_at_size():
     """h36m config (128 coarse + 16 importance samples = 272 MLP evaluations per ray, 16-d frame codes with a
     per-ray index, view layer K = 920) on all 262 144 rays of a 512x512 frame: the bf16 path is bitwise
     repeatable, agrees with the exact fp32 mode on the whole frame within the bf16 bound (and 60 dB), and a
-    strided 256-ray subset of BOTH equals the oracle (fp32 <= 1e-4, the north star's bound)."""
+    strided 256-ray subset of BOTH equals the oracle (fp32 <= 1e-4, the north star's bound); the compensated-fp16 mode
+    (pg_evalc2.hip with frame codes) is within 1e-4 of fp32 on the whole frame and of the oracle on the subset."""
     from bench import full_frame_rays
     from oracle import anerf_oracle as orc
     from posegen_amd.raycaster import HipRayCaster
@@ -61,12 +62,45 @@ def test_config4_h36m_full_frame_at_size():
     ocfg = oracle_cfg(cfg, tv, td)
     ref = orc.render_rays(rb_cpu[sel], skts_cpu, cyl_cpu, ocfg, torch_weights(wc), torch_weights(wf), cfg.n_samples,
                           cfg.n_importance, cams=cams.cpu()[sel])
-    for name, got, tol in (("fp32", e, 1e-4), ("bf16", a, 1e-2)):
+    # the compensated-fp16 mode on the same frame: the north star's 1e-4 at matrix-core speed, frame codes included
+    r.set_precision("fp16c")
+    f = r.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+    f2 = r.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0"):
+        assert torch.equal(f[k], f2[k]), k
+    dc = max(float((f[k] - e[k]).abs().max()) for k in ("rgb_map", "acc_map"))
+    print(f"config 4 full frame: fp16c vs fp32 max |d rgb / acc| {dc:.2e}")
+    assert dc <= 1e-4
+    for name, got, tol in (("fp32", e, 1e-4), ("bf16", a, 1e-2), ("fp16c", f, 1e-4)):
         err = max(float((got[k].cpu()[sel] - ref[k]).abs().max()) for k in ("rgb_map", "acc_map"))
         ps, mse = _psnr(got["rgb_map"].cpu()[sel], ref["rgb_map"])
         print(f"config 4 subset vs oracle, {name}: max |d| {err:.2e}, rgb MSE {mse:.2e}, PSNR {ps:.1f} dB")
         assert err <= tol and mse <= 1e-4
     r.close()
+
+
+def test_config4_on_chip_frame_codes_at_size(tmp_path):
+    """BASELINE config 4's frame (262 144 rays x (128 + 144) samples, a frame-code index per ray, some rays on the mean
+    code) through the on-chip variant of the 16x16x32 kernel (POSEGEN_ONCHIP=2: no per-ray records, the code's part of the
+    view layer from the table pg_api.hip ensure_ycode makes) against the record variant (POSEGEN_ONCHIP=0), a child process
+    each: no record launch, bitwise repeatable, and the maps agree within the modes' own rounding (the two forms round
+    the code's 16 products differently: bf16 4e-3, fp16 5e-4) -- every pass of every persistent workgroup, not only the
+    first one the 64-ray golden set reaches."""
+    import subprocess, sys
+    maps = {}
+    for mode in ("2", "0"):
+        out = str(tmp_path / f"maps_{mode}.pt")
+        run = subprocess.run([sys.executable, os.path.join(REPO, "tests", "diag", "h36m_onchip_frame.py"), out], capture_output=True,
+                             text=True, timeout=600, env=dict(os.environ, POSEGEN_ONCHIP=mode), cwd=REPO)
+        assert run.returncode == 0, run.stderr[-2000:]
+        maps[mode] = torch.load(out)
+    for prec, tol in (("bf16", 4e-3), ("fp16", 5e-4)):
+        a, b = maps["2"][prec], maps["0"][prec]
+        assert a["launches"] == (2, 0) and b["launches"] == (2, 2), (a["launches"], b["launches"])
+        assert a["repeatable"] and b["repeatable"]
+        d = {k: float((a[k] - b[k]).abs().max()) for k in ("rgb_map", "acc_map", "disp_map")}
+        print(f"config 4 frame, {prec}: on-chip frame codes vs per-ray records {d}")
+        assert all(torch.isfinite(a[k]).all() for k in d) and max(d.values()) <= tol, (prec, d)
 
 
 def test_rccl_world1_render_path_distributed_equals_render_path():
