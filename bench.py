@@ -540,7 +540,7 @@ def main():
                 result["roofline"]["issued_from"] = (f"SQ_INSTS_MFMA {ins:.4g} per launch x {per} FLOP (profiles/{tname}, commit "
                                                      f"{tj.get('commit', 'unrecorded')}) over points per launch x {flops_pt} algorithmic FLOP")
             break
-    if a.prec in ("bf16", "fp16", "fp16c") and world == 1:
+    if a.prec in ("bf16", "fp16", "fp16c") and world == 1 and not a.no_extras:    # (not in the profiled command: their launches carry the headline kernel's name)
         nf, z = r.stage_sample_coarse(rb, cyl, cfg.n_samples)
         result["roofline"]["limb_masks"] = dict(r.limb_skip_stats(0, rb, z, skts),
                                                 what=f"coarse launch of the benchmark frame ({cfg.n_samples} samples per ray), counted by the kernel: "
@@ -683,6 +683,23 @@ def main():
                         f"{c4.evals_per_ray()} MLP evals/ray, per-ray frame-code index, view layer K = {c4.ch_view_in}",
             "rays_per_s": rs, "ms_per_frame": msf, "kernel_tflops": tf, "frac": tf / peak, "avg_launch_ms": kms,
             "flop_per_ray": c4.flops_per_point() * c4.evals_per_ray()}}
+        if a.prec in ("bf16", "fp16"):      # the two forms of the 16x16x32 kernel on this workload (the default picks by sample count: records here)
+            r4 = cast4.renderer
+            forms = {}
+            for mode in ("records", "always"):
+                r4.set_onchip(mode)
+                r4.profile_read_aux()
+                rs_m, msf_m, tf_m, kms_m = timed_rays(r4, dev, rb, skts, cyl, c4, 2, cams=cams)
+                nrec, ms_rec = r4.profile_read_aux()
+                forms[mode] = {"rays_per_s": rs_m, "ms_per_frame": msf_m, "frac": tf_m / peak, "avg_launch_ms": kms_m,
+                               "record_launches_per_frame": nrec / 2.0, "record_ms_per_frame": ms_rec / 2.0,     # (two profiled frames)
+                               "frac_with_record_kernels": (tf_m / peak) * (2 * kms_m) / (2 * kms_m + ms_rec / 2.0)}
+            r4.set_onchip("auto")
+            result["workloads"]["h36m_512"]["forms"] = {
+                "per_ray_records": forms["records"], "on_chip": forms["always"], "default": "per_ray_records (pg_set_onchip AUTO: on chip up to 112 samples per ray)",
+                "what": "pg_set_onchip RECORDS / ALWAYS on the same frame: records = 8.75 KiB per ray through HBM and a record launch per eval launch "
+                        "(14.7 GB per frame, profiles/r5_h36m_records_traffic.json), on chip = frame-code rows from a host-made table, no records "
+                        "(3.7 GB per frame, profiles/r5_h36m_onchip_traffic.json)"}
         if a.prec != "fp16c":       # BASELINE config 4 in the north-star mode as well (no per-ray records since round 5: pg_evalc2.hip)
             cast4.renderer.set_precision("fp16c")
             rs, msf, tf, kms = timed_rays(cast4.renderer, dev, rb, skts, cyl, c4, 1, cams=cams)

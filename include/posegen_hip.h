@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 8
+#define PG_ABI_VERSION 9
 
 /* error codes */
 #define PG_OK 0
@@ -378,6 +378,21 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
  * cutoff_dist + 24 / (tau log2 e) has a cutoff weight 1 - sigmoid(tau (v - c)) below 2^-24, cutoff_embedder.py:139-146:
  * DESIGN.md 2.1).  Default on.  The two settings agree to ~1e-7 per skipped product. */
 int pg_set_far_skip(pg_handle* h, int on);
+
+/* Which form of the fused 16-bit kernel (pg_eval16r.hip) calls with >= 64 samples per ray take -- both compute
+ * encode_inputs + NeRF.forward (core/raycasters.py:476-577, core/networks/nerf.py:90-148), they differ in where the
+ * per-ray part (bone-local rays, the view layer's direction part, the frame code's part) is formed:
+ *   PG_ONCHIP_RECORDS (0): per-ray records in HBM (8.75 KiB per ray) written by a record kernel in front of every launch;
+ *   PG_ONCHIP_AUTO    (1): by sample count -- on chip up to 112 samples per ray, records above (the faster form of the
+ *                          two on MI355X: profiles/r5_ab_onchip_by_samples.txt); the default;
+ *   PG_ONCHIP_ALWAYS  (2): on chip whatever the sample count (no record workspace, a quarter of the HBM traffic at
+ *                          128 + 16 samples, 2 % slower there).
+ * The environment variable POSEGEN_ONCHIP = 0 / 1 / 2 sets the initial mode of handles created by the process.  The
+ * compensated kernel's older form (pg_evalc.hip, POSEGEN_EVALC2=0) follows modes 0 / non-0. */
+#define PG_ONCHIP_RECORDS 0
+#define PG_ONCHIP_AUTO 1
+#define PG_ONCHIP_ALWAYS 2
+int pg_set_onchip(pg_handle* h, int mode);
 
 /* Arithmetic of the TRAINING step (pg_train_forward / pg_train_backward), independent of the rendering precision
  * (pg_set_precision): PG_PREC_FP32 (default; the reference trains in fp32, core/trainer.py:232-275: gradients within 1e-4

@@ -218,13 +218,17 @@ int ensure_stream_ro(pg_handle* h, int which, int prec) {
 // sample-count rule.  The on-chip variant forms a ray's rows in every pass the ray has points in, the record variant once
 // per ray in a kernel in front: measured on one box (profiles/r5_ab_onchip_by_samples.txt, bf16 512 x 512 frames) the two
 // tie at 64 + 16 samples (31.7 / 31.8 ms), on-chip wins at 96 + 16 (43.3 / 43.6) and records win from 128 + 16 on (59.3 /
-// 58.0; with frame codes 59.7 / 58.2) -- at a cost of 8.75 KiB of HBM per ray.  POSEGEN_ONCHIP=0 forces the record
-// variants, POSEGEN_ONCHIP=2 the on-chip ones whatever the sample count (A/B, tests).
+// 58.0; with frame codes 59.7 / 58.2) -- at a cost of 8.75 KiB of HBM per ray.  pg_set_onchip (initial value: POSEGEN_ONCHIP = 0 / 1 / 2)
+// forces the record variants (0) or the on-chip ones whatever the sample count (2).
 constexpr int ONCHIP_MAX_S = 112;
-bool use_onchip(bool fc, long long pose_stride, int S, bool plain_only = false) {
-    static const int mode = [] { const char* e = std::getenv("POSEGEN_ONCHIP"); return e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1; }();
-    if (plain_only) return mode != 0 && !fc && pose_stride == 0;
-    return mode == 2 || (mode == 1 && S <= ONCHIP_MAX_S);
+int onchip_mode_from_env() {
+    const char* e = std::getenv("POSEGEN_ONCHIP");
+    return e && e[0] == '0' ? PG_ONCHIP_RECORDS : e && e[0] == '2' ? PG_ONCHIP_ALWAYS : PG_ONCHIP_AUTO;
+}
+bool use_onchip(const pg_handle* h, bool fc, long long pose_stride, int S, bool plain_only = false) {
+    const int mode = h->onchip_mode;
+    if (plain_only) return mode != PG_ONCHIP_RECORDS && !fc && pose_stride == 0;
+    return mode == PG_ONCHIP_ALWAYS || (mode == PG_ONCHIP_AUTO && S <= ONCHIP_MAX_S);
 }
 
 // The frame code's part of the view layer for every code (and the mean row, embedding.py:25-26), as the on-chip variant reads it:
@@ -336,9 +340,9 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
 int ensure_mode_streams(pg_handle* h, int which, int mode) {
     auto one = [&](int prec) {
         const bool fc = h->cfg.framecode_ch > 0;
-        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(fc, 0, FACT_MIN_S) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
+        if (is_shape_a(prec) && use_fact(prec, FACT_MIN_S)) return use_onchip(h, fc, 0, FACT_MIN_S) ? ensure_stream_ro(h, which, prec) : ensure_stream_r(h, which, prec);
         if (prec == PG_PREC_FP16C && use_evalc2(FACT_MIN_S)) return ensure_c2(h, which);
-        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(fc, 0, FACT_MIN_S, true) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
+        if (prec == PG_PREC_FP16C && use_comp_rec(FACT_MIN_S)) return use_onchip(h, fc, 0, FACT_MIN_S, true) ? ensure_stream_co(h, which) : ensure_stream_cr(h, which);
         return ensure_stream(h, which, prec, use_fact(prec, FACT_MIN_S));
     };
     if (mode != PG_PREC_FP16M) return one(mode);
@@ -377,10 +381,10 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
     const bool fact = compk || (!points && !pnoise && use_fact(prec, S));
     const bool sa = is_shape_a(prec);
     const bool fc = h->cfg.framecode_ch > 0;
-    const bool onchip = sa && fact && (!dbg || (dbg_stage == 97 && pose_stride == 0 && !fc)) && use_onchip(fc, pose_stride, S);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
+    const bool onchip = sa && fact && (!dbg || (dbg_stage == 97 && pose_stride == 0 && !fc)) && use_onchip(h, fc, pose_stride, S);     // the 16x16x32 kernel without per-ray records (97: its limb-mask counters)
     const bool recs = sa && fact && !onchip;                      // per-ray records + the 16x16x32 kernel
     const bool c2 = compk && (!dbg || dbg_stage == 99 || dbg_stage == 97) && use_evalc2(S);      // out tiles over the waves (pg_evalc2.hip): any pose stride, frame codes or not
-    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(fc, pose_stride, S, true);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
+    const bool conchip = !c2 && compk && use_comp_rec(S) && (!dbg || dbg_stage == 98 || dbg_stage == 99) && use_onchip(h, fc, pose_stride, S, true);   // (98 / 99: diagnosis builds' dumps)   // the record variant of pg_evalc.hip without per-ray records
     const bool crec = !c2 && compk && use_comp_rec(S) && !conchip;       // per-ray records + the record variant of pg_evalc.hip
     int rc = onchip ? ensure_stream_ro(h, which, prec) : recs ? ensure_stream_r(h, which, prec) : c2 ? ensure_c2(h, which)
            : conchip ? ensure_stream_co(h, which) : crec ? ensure_stream_cr(h, which) : ensure_stream(h, which, prec, fact);
@@ -535,6 +539,7 @@ int pg_create(const pg_config* cfg, int n_devices, const int* device_ids, pg_han
     if (cfg->density_act != PG_ACT_RELU && cfg->density_act != PG_ACT_SOFTPLUS)
         return pg_fail(nullptr, PG_EINVAL, "pg_create: density_act must be PG_ACT_RELU or PG_ACT_SOFTPLUS, got %d", cfg->density_act);
     pg_handle* h = new (std::nothrow) pg_handle();
+    if (h) h->onchip_mode = onchip_mode_from_env();
     if (!h) return pg_fail(nullptr, PG_ENOMEM, "pg_create: out of host memory");
     h->cfg = *cfg;
     h->device = device_ids ? device_ids[0] : 0;
@@ -752,6 +757,14 @@ int pg_set_far_skip(pg_handle* h, int on) {
     return PG_OK;
 }
 
+int pg_set_onchip(pg_handle* h, int mode) {
+    if (!h) return pg_fail(nullptr, PG_EINVAL, "pg_set_onchip: null handle");
+    if (mode < PG_ONCHIP_RECORDS || mode > PG_ONCHIP_ALWAYS) return pg_fail(h, PG_EINVAL, "pg_set_onchip: mode must be 0 (records), 1 (by sample count) or 2 (on chip), got %d", mode);
+    h->onchip_mode = mode;
+    PG_FORWARD(h, pg_set_onchip(hh, mode));
+    return PG_OK;
+}
+
 int pg_set_train_precision(pg_handle* h, int precision) {
     if (!h) return pg_fail(nullptr, PG_EINVAL, "null handle");
     if (precision != PG_PREC_FP32 && precision != PG_PREC_BF16)
@@ -927,7 +940,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
     const bool fact = use_fact(precision, FACT_MIN_S);
     const bool compk = use_comp_kernel(precision, FACT_MIN_S, false);
     if (sa && fact) {                        // 16x16x32 kernel: reported in 32x32x16 equivalents (32 768 FLOP each)
-        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0, FACT_MIN_S) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(h, fc, 0, FACT_MIN_S) ? pgp::R::NCHUNK_OC : pgp::R::NCHUNK) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::R::MFMA16_PER_GROUP / 2;
         return PG_OK;
     }
@@ -937,7 +950,7 @@ int pg_query(const pg_handle* h, int precision, int64_t* stream_bytes, int64_t* 
         return PG_OK;
     }
     if (compk && use_comp_rec(FACT_MIN_S)) {     // record variant of the compensated kernel (the usual case)
-        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(fc, 0, FACT_MIN_S, true) ? pgp::C::NCHUNK_OC : pgp::C::NCHUNK_R) * CHUNK_BYTES;
+        if (stream_bytes) *stream_bytes = (int64_t)(use_onchip(h, fc, 0, FACT_MIN_S, true) ? pgp::C::NCHUNK_OC : pgp::C::NCHUNK_R) * CHUNK_BYTES;
         if (mfma_per_group) *mfma_per_group = pgp::C::MFMA_PER_GROUP_R;
         return PG_OK;
     }

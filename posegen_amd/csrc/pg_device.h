@@ -228,7 +228,9 @@ struct Stream {
 #else
         if (dma_wave()) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PER) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(PG_ABL_NOBARRIER)      // timing ablation only (racy, wrong results): what ANY scheme without a workgroup barrier per chunk could gain at most
         __builtin_amdgcn_s_barrier();
+#endif
 #endif
         cur_src = next_off + (wave - dma_base()) * (PER * 1024);
         cur_dst = fill_slot * CHUNK_BYTES + (wave - dma_base()) * (PER * 1024);

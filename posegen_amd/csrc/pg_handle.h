@@ -58,6 +58,7 @@ struct pg_handle {
     hipStream_t own_stream = nullptr;
     float* d_pose = nullptr;         // [24*16 + 5 + pad] skts + cyl of the frame being rendered
     bool far_skip = true;            // pg_set_far_skip (test / measurement aid)
+    int onchip_mode = PG_ONCHIP_AUTO;        // pg_set_onchip (initial value: POSEGEN_ONCHIP)
     int train_precision = PG_PREC_FP32;      // pg_set_train_precision: arithmetic of the training step (fp32 like the reference, or bf16)
     bool profiling = false;
     std::vector<hipEvent_t> ev_free;

@@ -138,6 +138,15 @@ class HipRenderer:
             self._check(self.lib.pg_set_chunk(self.handle, int(chunk)))
             self._chunk = int(chunk)
 
+    def set_onchip(self, mode="auto"):
+        """Which form of the 16x16x32 kernel calls with >= 64 samples per ray take (pg_set_onchip): "records" (per-ray records in
+        HBM), "auto" (on chip up to 112 samples per ray: the faster of the two, the default) or "always" (on chip whatever the
+        sample count: no record workspace)."""
+        modes = {"records": 0, "auto": 1, "always": 2, 0: 0, 1: 1, 2: 2}
+        if mode not in modes:
+            raise ValueError(f"set_onchip: mode must be 'records', 'auto' or 'always', not {mode!r}")
+        self._check(self.lib.pg_set_onchip(self.handle, modes[mode]))
+
     def set_far_skip(self, on=True):
         """Test / measurement aid (pg_set_far_skip): off = the fused kernels compute every limb for every point."""
         self._check(self.lib.pg_set_far_skip(self.handle, 1 if on else 0))

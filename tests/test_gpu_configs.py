@@ -79,28 +79,45 @@ def test_config4_h36m_full_frame_at_size():
     r.close()
 
 
-def test_config4_on_chip_frame_codes_at_size(tmp_path):
+def test_config4_on_chip_frame_codes_at_size():
     """BASELINE config 4's frame (262 144 rays x (128 + 144) samples, a frame-code index per ray, some rays on the mean
-    code) through the on-chip variant of the 16x16x32 kernel (POSEGEN_ONCHIP=2: no per-ray records, the code's part of the
-    view layer from the table pg_api.hip ensure_ycode makes) against the record variant (POSEGEN_ONCHIP=0), a child process
-    each: no record launch, bitwise repeatable, and the maps agree within the modes' own rounding (the two forms round
-    the code's 16 products differently: bf16 4e-3, fp16 5e-4) -- every pass of every persistent workgroup, not only the
-    first one the 64-ray golden set reaches."""
-    import subprocess, sys
-    maps = {}
-    for mode in ("2", "0"):
-        out = str(tmp_path / f"maps_{mode}.pt")
-        run = subprocess.run([sys.executable, os.path.join(REPO, "tests", "diag", "h36m_onchip_frame.py"), out], capture_output=True,
-                             text=True, timeout=600, env=dict(os.environ, POSEGEN_ONCHIP=mode), cwd=REPO)
-        assert run.returncode == 0, run.stderr[-2000:]
-        maps[mode] = torch.load(out)
+    code) through the on-chip variant of the 16x16x32 kernel (pg_set_onchip ALWAYS: no per-ray records, the code's part of
+    the view layer from the table pg_api.hip ensure_ycode makes) against the record variant (RECORDS; what AUTO picks at
+    128 samples): no record launch, bitwise repeatable, and the maps agree within the modes' own rounding (the two forms
+    round the code's 16 products differently: bf16 4e-3, fp16 5e-4) -- every pass of every persistent workgroup, not only
+    the first one the 64-ray golden set reaches."""
+    from bench import full_frame_rays
+    from posegen_amd.raycaster import HipRayCaster
+    cfg = h36m_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 0), device=DEV, precision="bf16")
+    r = c.renderer
+    rb, skts, cyl, *_ = full_frame_rays(512, 512, DEV)
+    n = rb.shape[0]
+    cams = (torch.arange(n, device=DEV) % cfg.n_framecodes).float()
+    cams[5::7] = -1.0           # (rays without a frame: the mean code, embedding.py:25-26)
+    keys = ("rgb_map", "acc_map", "disp_map")
     for prec, tol in (("bf16", 4e-3), ("fp16", 5e-4)):
-        a, b = maps["2"][prec], maps["0"][prec]
-        assert a["launches"] == (2, 0) and b["launches"] == (2, 2), (a["launches"], b["launches"])
-        assert a["repeatable"] and b["repeatable"]
-        d = {k: float((a[k] - b[k]).abs().max()) for k in ("rgb_map", "acc_map", "disp_map")}
+        r.set_precision(prec)
+        maps = {}
+        for mode, want_records in (("always", 0), ("records", 2), ("auto", 2)):
+            r.set_onchip(mode)
+            r.profile_enable(True)
+            r.profile_read(); r.profile_read_aux()
+            a = r.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+            torch.cuda.synchronize()
+            launches, _, _ = r.profile_read()
+            recs, _ = r.profile_read_aux()
+            r.profile_enable(False)
+            assert (launches, recs) == (2, want_records), (prec, mode, launches, recs)
+            b = r.render_rays(rb, skts, cyl, cams=cams, want_alpha=False)
+            assert all(torch.equal(a[k], b[k]) for k in keys), (prec, mode)
+            maps[mode] = a
+        r.set_onchip("auto")
+        assert all(torch.equal(maps["auto"][k], maps["records"][k]) for k in keys)
+        d = {k: float((maps["always"][k] - maps["records"][k]).abs().max()) for k in keys}
         print(f"config 4 frame, {prec}: on-chip frame codes vs per-ray records {d}")
-        assert all(torch.isfinite(a[k]).all() for k in d) and max(d.values()) <= tol, (prec, d)
+        assert all(torch.isfinite(maps["always"][k]).all() for k in keys) and max(d.values()) <= tol, (prec, d)
+    r.close()
 
 
 def test_rccl_world1_render_path_distributed_equals_render_path():

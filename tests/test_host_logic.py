@@ -454,7 +454,14 @@ def test_hazard_audit_flags_a_transcendental_result_read_by_the_next_instruction
     good = head + "\tv_cos_f32_e32 v141, v194\n\ts_nop 0\n\tv_cvt_pk_f16_f32 v198, v140, v141\n\ts_endpgm\n"
     chain = head + "\tv_rsq_f32_e32 v1, v2\n\tv_sin_f32_e32 v3, v1\n\tv_mul_f32_e32 v4, v5, v6\n\ts_endpgm\n"      # trans -> trans is not the hazard
     wide = head + "\tv_exp_f32_e32 v9, v2\n\tv_mfma_f32_32x32x16_f16 a[0:15], v[8:11], v[4:7], a[0:15]\n\ts_endpgm\n"  # a register range
-    for name, text, rc in (("bad", bad, 1), ("good", good, 0), ("chain", chain, 0), ("wide", wide, 1)):
+    # the destination is a source too: accumulate opcodes, SDWA / DPP forms
+    fmac = head + "\tv_exp_f32_e32 v5, v2\n\tv_fmac_f32_e32 v5, v6, v7\n\ts_endpgm\n"
+    pkfmac = head + "\tv_rcp_f32_e32 v5, v2\n\tv_pk_fmac_f16 v5, v6, v7\n\ts_endpgm\n"
+    dot = head + "\tv_sqrt_f32_e32 v5, v2\n\tv_dot2c_f32_f16 v5, v6, v7\n\ts_endpgm\n"
+    sdwa = head + "\tv_log_f32_e32 v5, v2\n\tv_add_f32_sdwa v5, v6, v7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\ts_endpgm\n"
+    fmac_ok = head + "\tv_exp_f32_e32 v5, v2\n\tv_fmac_f32_e32 v8, v6, v7\n\ts_endpgm\n"
+    for name, text, rc in (("bad", bad, 1), ("good", good, 0), ("chain", chain, 0), ("wide", wide, 1), ("fmac", fmac, 1),
+                           ("pkfmac", pkfmac, 1), ("dot", dot, 1), ("sdwa", sdwa, 1), ("fmac_ok", fmac_ok, 0)):
         f = tmp_path / f"{name}.s"
         f.write_text(text)
         r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)

@@ -40,7 +40,15 @@ def vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
+# opcodes whose destination is a source as well (accumulate forms): the destination token counts as read
+ACCUM = re.compile(r"v_(?:pk_)?(?:fmac|mac|fmaak|madak)_|v_dot\d|v_mfma_|v_smfmac_|v_(?:cndmask|mov)\w*_(?:sdwa|dpp)|v_\w+_(?:sdwa|dpp)\b")
+
+
 def trans_hazards(kernel_text):
+    """non-transcendental VALU instructions that read the result of the transcendental right in front of them (a transcendental
+    reader runs in the same quarter-rate unit, in order: LLVM's hasTransForwardingHazard applies to non-TRANS readers only).
+    Accumulate opcodes (v_fmac / v_mac / v_pk_fmac / v_dot*, MFMA forms whose vdst is tied to the accumulator) and the
+    SDWA / DPP forms (a partial write preserves, i.e. reads, the destination) read their destination register too."""
     hits, prev = [], None
     for ln in kernel_text.split("\n"):
         code = ln.split(";")[0].strip()
@@ -48,9 +56,12 @@ def trans_hazards(kernel_text):
             continue
         m = TRANS.match(code)
         if prev is not None and code.startswith("v_") and not m:
+            toks = re.split(r"[,\s]+", code)
             srcs = set()
-            for t in re.split(r"[,\s]+", code)[2:]:
+            for t in toks[2:]:
                 srcs |= vregs(t)
+            if ACCUM.match(toks[0]) and len(toks) > 1:
+                srcs |= vregs(toks[1])
             if prev in srcs:
                 hits.append(code)
         prev = int(m.group(1)) if m else None

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round profiles on the GPU box: kernel stats + separate PMC passes of the default bench workload.
-# usage: tools/collect_profiles.sh <tag> [bench args...]   (writes gpurun_out/prof_<tag>/)
+# usage: [PROG=tools/x.py] [PASSES="stats fetch write mfma"] tools/collect_profiles.sh <tag> [bench args...]   (writes gpurun_out/prof_<tag>/)
 set -e -o pipefail
 tag=$1; shift
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes --no-extras $*"
+# PROG=<script under the repo> profiles that program instead of the bench (tools/run_h36m.py: config 4's frame)
+if [ -n "$PROG" ]; then B="python3 $root/$PROG"; else B="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes --no-extras $*"; fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $B > $out/write.log 2>&1
