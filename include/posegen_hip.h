@@ -417,7 +417,7 @@ int pg_profile_read_aux(pg_handle* h, int64_t* n_launches, double* total_ms);
  * view_fact != 0 selects the stream of the factorised view layer the 16-bit kernels use
  * when a ray has >= 64 samples; view_fact == 2: the record variant of the compensated kernel;
  * view_fact == 3: the on-chip variant of the 16x16x32 kernel or of the compensated kernel's record form (no per-ray records: one pose,
- * no frame codes). */
+ * no frame codes); view_fact == 4 with PG_PREC_FP16C: the weight image of pg_evalc2.hip (pg_program.h T; bias_out: the 16-row table). */
 int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tensors,
                   int framecode_ch, int precision, int view_fact, uint8_t* stream_out, int64_t stream_cap,
                   int64_t* stream_bytes, float* bias_out /* 82*32 floats or NULL */,

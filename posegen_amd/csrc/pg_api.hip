@@ -407,11 +407,13 @@ int launch_eval_one(pg_handle* h, void* stream, int which, long long n, int S, c
         // the padding rays behind the last record are fetched by the last passes (their values are multiplied by
         // zero weights at most): keep them finite whatever the buffer held before.  The record kernels write rays
         // < n only, so the padding of an (n, record size) pair stays zero until another pair moves it.
-        if (h->rec_pad_n != n || h->rec_pad_y != y_bytes) {
+        // (every writer of h->rec -- the two record kernels -- stores rays < n only; anything else that is ever handed the
+        // buffer must reset rec_pad_n to -1, as ensure_rec does)
+        if (h->rec_pad_n != n || h->rec_pad_y != y_bytes || h->rec_pad_stream != stream) {
             PG_HIP(h, hipMemsetAsync(h->rec + (size_t)n * y_bytes, 0, (size_t)REC_PAD_RAYS * y_bytes, static_cast<hipStream_t>(stream)));
             PG_HIP(h, hipMemsetAsync(h->rec + (size_t)(n + REC_PAD_RAYS) * y_bytes + (size_t)n * REC_AB_BYTES, 0,
                                      (size_t)REC_PAD_RAYS * REC_AB_BYTES, static_cast<hipStream_t>(stream)));
-            h->rec_pad_n = n; h->rec_pad_y = y_bytes;
+            h->rec_pad_n = n; h->rec_pad_y = y_bytes; h->rec_pad_stream = stream;
         }
     }
     a.cutoff = h->d_cut;
@@ -840,7 +842,9 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     std::vector<uint8_t> packed;
     const bool rprog = view_fact != 0 && is_shape_a(precision);       // the 16x16x32 program of pg_eval16r.hip
     const bool crec = view_fact >= 2 && precision == PG_PREC_FP16C;     // record variant of pg_evalc.hip (3: its on-chip form)
-    const int rc = rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed, view_fact == 3)
+    const bool c2 = view_fact == 4 && precision == PG_PREC_FP16C;       // the weight image of pg_evalc2.hip (pg_program.h T)
+    const int rc = c2 ? pgpack::pack_c2(tensors_of(ns, cfg), framecode_ch > 0, packed)
+                 : rprog ? pgpack::pack_stream_r(tensors_of(ns, cfg), precision, packed, view_fact == 3)
                          : pgpack::pack_stream(tensors_of(ns, cfg), precision, framecode_ch > 0, view_fact != 0, packed, nullptr, crec,
                                                crec && view_fact == 3);
     if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack: packing failed (%d)", rc);
@@ -852,7 +856,7 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     }
     if (bias_out) {
         std::vector<float> bias;
-        if (rprog) pgpack::pack_bias_s(tensors_of(ns, cfg), bias);
+        if (rprog || c2) pgpack::pack_bias_s(tensors_of(ns, cfg), bias);
         else pgpack::pack_bias(tensors_of(ns, cfg), bias);
         std::memcpy(bias_out, bias.data(), bias.size() * sizeof(float));
     }

@@ -52,6 +52,7 @@ struct pg_handle {
     size_t rec_bytes = 0;
     long long rec_pad_n = -1;        // (n, Y bytes per ray) whose padding records are currently zero (-1: none)
     int rec_pad_y = 0;
+    void* rec_pad_stream = nullptr;  // the stream that memset was issued on: a call on another stream zeroes again (no ordering between streams)
     // in-process multi-device rendering (pg_render_frames): the primary handle owns one sub-handle per
     // further device; every handle has a stream and a small pose buffer of its own for that path
     std::vector<pg_handle*> peers;

@@ -100,6 +100,26 @@ class BoxPixelIds:
     def __iter__(self):
         return (self[i] for i in range(len(self)))
 
+    def tolist(self):
+        """The reference's return type: a plain list of int64 id tensors, one per frame (builds them all)."""
+        return list(self)
+
+    def __array__(self, dtype=None, copy=None):
+        """numpy view of the sequence: an object array of the per-frame id arrays (frames have different box sizes)."""
+        out = np.empty(len(self), dtype=object)
+        for i in range(len(self)):
+            out[i] = self[i].numpy() if dtype is None else self[i].numpy().astype(dtype)
+        return out
+
+    def __add__(self, other):
+        return self.tolist() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.tolist()
+
+    def __reduce__(self):               # pickles as what it stands for: the list of id tensors
+        return (list, (self.tolist(),))
+
 
 def frame_boxes(renderer, poses, H, W, focal, kps=None, cylinder_params=None, centers=None, ext_scale=0.00035):
     """Bounding cylinders and integer boxes of `len(poses)` frames without the pixel grids: (cyls [n_pose,5] float32

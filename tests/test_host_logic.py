@@ -435,6 +435,15 @@ def test_box_pixel_ids_are_the_reference_valid_idxs_built_lazily():
     for i, (rows, cols, h, w, *_rest) in enumerate(grids):
         assert torch.equal(lazy[i], rows * w + cols)
     assert sum(len(v) for v in lazy) == sum(lazy.counts())
+    # list-likeness of the reference's return type: a plain list on request, concatenation, numpy, pickling
+    import pickle
+    as_list = lazy.tolist()
+    assert isinstance(as_list, list) and all(torch.equal(a, b) for a, b in zip(as_list, lazy))
+    assert isinstance(lazy + [torch.zeros(1)], list) and len(lazy + [torch.zeros(1)]) == 4 and len([1] + lazy) == 4
+    arr = np.asarray(lazy)
+    assert arr.dtype == object and arr.shape == (3,) and np.array_equal(arr[1], lazy[1].numpy())
+    back = pickle.loads(pickle.dumps(lazy))
+    assert isinstance(back, list) and all(torch.equal(a, b) for a, b in zip(back, lazy))
     c2, b2, meta = frame_boxes(object(), torch.tensor(c2ws), H, W, focals, kps=torch.tensor(kps), ext_scale=0.001)   # no pose_boxes: host route
     assert torch.equal(torch.as_tensor(c2), torch.as_tensor(cyls))
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(b2, bboxes))

@@ -64,7 +64,7 @@ def pack(weights, cfg, prec, fact=False):
     rc = lib.pg_debug_pack(ptrs, shp, 24, cfg.framecode_ch, prec, int(fact), buf.ctypes.data, size.value, C.byref(size),
                            bias.ctypes.data, C.byref(chunk))
     assert rc == 0, lib.pg_last_error(None)
-    if (fact and fact != 3 and prec != PREC_FP16C) or fact == 2:      # Y-stage weights (the compensated kernel: record variant only)
+    if (fact and fact not in (3, 4) and prec != PREC_FP16C) or fact == 2:      # Y-stage weights (the compensated kernel: record variant only)
         n = C.c_int64()
         rc = lib.pg_debug_pack_vy(ptrs, shp, 24, cfg.framecode_ch, prec, None, 0, C.byref(n))
         assert rc == 0, lib.pg_last_error(None)
@@ -584,3 +584,146 @@ def test_packed_stream_reproduces_mlp(prec, quant, tol, fc, fact):
         raw, n_chunks = emulate(stream, bias, chunk_bytes, prec, x_em, cfg, None)
     assert n_chunks * chunk_bytes == stream.size, "kernel program and packer disagree on the chunk count"
     np.testing.assert_allclose(raw, ref, rtol=0, atol=tol * max(1.0, float(np.abs(ref).max()) / 10))
+
+
+# ---- the weight image of pg_evalc2.hip (pg_program.h T, pg_pack.cpp pack_c2): no stream; one 4-KiB block
+# [tile t of the wave][plane] per (k-unit, wave), a B-fragment section for the view layer's direction part, two compact
+# tables for the alpha row and the rgb rows ----
+T_NW, T_FRAG, T_KBLK = 8, 1024, 4096
+T_SEC_X, T_SEC_H, T_SEC_AV = XU16 * T_NW * T_KBLK, HU16 * T_NW * T_KBLK, HU16 * 4 * T_KBLK
+T_NSLOT_Y = J + 1
+T_SEC_Y = T_NSLOT_Y * NTV16 * 2 * T_FRAG
+T_ALPHA_STRIDE, T_RGB_STRIDE = 5 * 16, 13 * 16
+T_SMALL_ALPHA, T_SMALL_RGB = HU16 * 2 * T_ALPHA_STRIDE, (VW // 32) * 2 * T_RGB_STRIDE
+
+
+def t_off_hid(hs):
+    return T_SEC_X + hs * T_SEC_H + (T_SEC_X if hs >= 5 else 0)
+
+
+T_OFF_X5 = T_SEC_X + 5 * T_SEC_H
+T_OFF_AV = t_off_hid(7)
+T_OFF_Y = T_OFF_AV + T_SEC_AV
+T_OFF_SMALL = T_OFF_Y + T_SEC_Y
+T_TOTAL = T_OFF_SMALL + T_SMALL_ALPHA + T_SMALL_RGB
+
+
+def emulate_t(img, bias16, x, cfg, tray, wpt):
+    """x: [pts, 432] density input, view input = wpt (x) tray (+ the frame code in tray[J]) -> raw [pts, 4] through the
+    image as pg_evalc2.hip reads it: wave w's block of k-unit u = its two out tiles 2 w, 2 w + 1, two planes each
+    (lane (g, row): k = 8 g + e of the unit); every product W x = plane0 . x1 + plane1 . x2 with the activation pair
+    (x1, x2) = (f16(x), f16(x1 + 129 (x - x1))) the kernel forms (pg_comp.h) -- i.e. (S - 1) w1 x1 + w2 x2."""
+    S = 129.0
+    npt = x.shape[0]
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+
+    def split(a):
+        a = a.astype(np.float32)
+        a1 = f16(a)
+        return a1, f16(a1 + np.float32(S) * (a - a1))
+
+    def frag(off):           # one A / B fragment -> [row 16, g 4, e 8]
+        return img[off:off + T_FRAG].view(np.float16).astype(np.float64).reshape(4, 16, 8).transpose(1, 0, 2)
+
+    def seq_pair(fn, nu, src):       # the B planes of a sequence: [plane][g, 8 nu, pt]
+        v = np.zeros((4, nu * 8, npt), dtype=np.float32)
+        for g in range(4):
+            for i in range(nu * 8):
+                ch = fn(i, g)
+                if ch >= 0:
+                    v[g, i] = src[:, ch]
+        return split(v)
+
+    def bias_tile(t):
+        return np.repeat(bias16[t * 16:(t + 1) * 16].reshape(16, 1).astype(np.float64), npt, axis=1)
+
+    def trunk(off, nu, pair, acc):           # acc: 16 out tiles of [16, pts]
+        for u in range(nu):
+            for w in range(T_NW):
+                for tt in range(2):
+                    f0 = off + ((u * T_NW + w) * 4 + tt * 2) * T_FRAG
+                    for pl in range(2):
+                        acc[2 * w + tt] += np.einsum("rge,gep->rp", frag(f0 + pl * T_FRAG), pair[pl][:, 8 * u:8 * u + 8, :].astype(np.float64))
+        return acc
+
+    def hidden_pair(tiles):
+        act = np.maximum(np.concatenate(tiles, 0), 0).astype(np.float32)       # [channels, pts]
+        return seq_pair(hseq16_channel, act.shape[0] // 32, act.T)
+
+    xp = seq_pair(xseq16_channel, XU16, x)
+    tiles = trunk(0, XU16, xp, [bias_tile(o) for o in range(NT16)])
+    for hs in range(7):              # layers 1..7; layer 5 = the skip layer: hidden part + the density input again
+        tiles = trunk(t_off_hid(hs), HU16, hidden_pair(tiles), [bias_tile((hs + 1) * NT16 + o) for o in range(NT16)])
+        if hs == 4:
+            tiles = trunk(T_OFF_X5, XU16, xp, tiles)
+    hp = hidden_pair(tiles)
+    # alpha from the compact table: entry g of [u][plane] = row 0, k = 8 g + e
+    sigma = np.full(npt, float(bias16[BS_ALPHA * 16]))
+    for u in range(HU16):
+        for pl in range(2):
+            tab = img[T_OFF_SMALL + (u * 2 + pl) * T_ALPHA_STRIDE:][:64].view(np.float16).astype(np.float64).reshape(4, 8)
+            sigma += np.einsum("ge,gep->p", tab, hp[pl][:, 8 * u:8 * u + 8, :].astype(np.float64))
+    # folded view layer, trunk part: tile pair v = tiles 2 v, 2 v + 1 of k-unit u
+    vt = [bias_tile(BS_VIEWF + o) for o in range(NTV16)]
+    for u in range(HU16):
+        for v in range(4):
+            for tt in range(2):
+                f0 = T_OFF_AV + ((u * 4 + v) * 4 + tt * 2) * T_FRAG
+                for pl in range(2):
+                    vt[2 * v + tt] += np.einsum("rge,gep->rp", frag(f0 + pl * T_FRAG), hp[pl][:, 8 * u:8 * u + 8, :].astype(np.float64))
+    # direction part: Y[slot][out] = W_vd[:, slot block] . T[slot] (the ray's 27 view values / the 16 code values, split like an
+    # activation), then sum_slots w_slot(point) Y[slot] (w = 1 for the code)
+    fc = bool(cfg.framecode_ch)
+    for s in range(J + (1 if fc else 0)):
+        j = PERM16[s] if s < J else J
+        t1, t2 = split(tray[j].reshape(4, 8))
+        for tt in range(NTV16):
+            f0 = T_OFF_Y + ((s * NTV16 + tt) * 2) * T_FRAG
+            y = np.einsum("rge,ge->r", frag(f0), t1.astype(np.float64)) + np.einsum("rge,ge->r", frag(f0 + T_FRAG), t2.astype(np.float64))
+            wj = wpt[:, j].astype(np.float64) if j < J else np.ones(npt)
+            vt[tt] += np.outer(y, wj)
+    gp = hidden_pair(vt)
+    rgb = np.repeat(bias16[BS_RGB * 16:BS_RGB * 16 + 3].reshape(3, 1).astype(np.float64), npt, axis=1)
+    for u in range(VW // 32):
+        for pl in range(2):
+            tab = img[T_OFF_SMALL + T_SMALL_ALPHA + (u * 2 + pl) * T_RGB_STRIDE:][:12 * 16].view(np.float16).astype(np.float64).reshape(4, 3, 8)
+            rgb += np.einsum("gre,gep->rp", tab, gp[pl][:, 8 * u:8 * u + 8, :].astype(np.float64))
+    return np.stack([rgb[0], rgb[1], rgb[2], sigma], -1)
+
+
+@pytest.mark.parametrize("fc", [False, True])
+def test_tile_split_weight_image_reproduces_mlp(fc):
+    """pack_c2 (the weights of pg_evalc2.hip: out tiles split over the waves, no stream) read back as the kernel reads
+    them, with the kernel's compensated products, against the fp32 oracle on the same points: <= 1e-4 (plain fp16
+    is at 4e-3 on this input) -- layout, plane pairing, the skip layer's two sections, the compact alpha / rgb tables,
+    the direction section in slot order and the frame code's pseudo slot."""
+    try:
+        _ffi.load_library()
+    except _ffi.HipLibraryError as e:
+        pytest.skip(str(e))
+    cfg = h36m_config() if fc else surreal_config()
+    w = syn.make_weights(cfg, 3)
+    img, bias16, _, _ = pack(w, cfg, PREC_FP16C, 4)
+    assert img.size == T_TOTAL
+    rng = np.random.RandomState(0)
+    npt = 16
+    x = rng.uniform(-1, 1, size=(npt, 1080)).astype(np.float32)
+    x[:, :360] *= rng.uniform(0, 1, size=(npt, 1)).astype(np.float32)
+    tray = np.zeros((J + 1, 32), dtype=np.float32)
+    tray[:J, :27] = rng.uniform(-1, 1, size=(J, 27))
+    wpt = rng.uniform(0, 1, size=(npt, J)).astype(np.float32)
+    for j in range(J):
+        for k in range(27):
+            x[:, 432 + vd_channel(j, k)] = wpt[:, j] * tray[j, k]
+    ocfg = oracle_cfg(cfg, 79.6, 79.6)
+    tw = {k: torch.tensor(v) for k, v in w.items()}
+    if fc:
+        idx = np.full((npt, 1), 5, dtype=np.float32)                   # one ray, one frame code
+        tray[J, :16] = w["framecodes.codes.weight"][5]
+        ref = orc.mlp_forward(torch.tensor(np.concatenate([x, idx], 1)), tw, ocfg).numpy()
+    else:
+        ref = orc.mlp_forward(torch.tensor(x), tw, ocfg).numpy()
+    raw = emulate_t(img, bias16, x[:, :432], cfg, tray, wpt)
+    err = float(np.abs(raw - ref).max())
+    print(f"pg_evalc2 weight image emulation vs fp32 oracle: {err:.2e} (|ref| max {np.abs(ref).max():.2f})")
+    assert err <= 1e-4 * max(1.0, float(np.abs(ref).max()) / 10)
