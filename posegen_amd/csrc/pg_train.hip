@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -506,6 +507,141 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
     if (!A_KCONT && rowsum && t < TB && m0 + t < M) rs_part[((long long)blockIdx.z * gridDim.x + blockIdx.x) * M + m0 + t] = rs;
 }
 
+// ---- a 256 x 256 layer as a PERSISTENT kernel (16-bit mode: the forward and dX GEMMs of the trunk's plain layers and of
+// feature_linear): C[m][n] = epilogue(sum_k A[m][k] B[n][k]), N = K = 256, both operands bf16 and k-contiguous, bf16 result.
+// A 256-wide layer moves 0.34 GB for 43 GFLOP: it is bound by HBM, so the kernel is built around the stream of activation
+// rows, not around the MFMAs.
+//   * One workgroup of 8 waves per CU strides over 128-row tiles.  The layer's weights live in REGISTERS for the whole launch:
+//     wave w holds rows 32 w .. + 31 of B as 16 A-operand fragments of v_mfma_f32_32x32x16_bf16 (64 registers) and computes those
+//     32 outputs for all 128 rows of every tile (four accumulator tiles; every wave reads the whole activation tile from LDS:
+//     512 KiB per tile and CU = 4 k cycles, as many as the tile's MFMAs and less than half of what its 128 KiB take on HBM).
+//   * The activation tile travels HBM -> LDS by LDS-DMA straight into MFMA-fragment order (fragment (row tile, k-step) = 1 KiB =
+//     64 lanes x 16 B, lane (row, k half) fetching its own 16 bytes): no register staging, no transposing stores, conflict-free
+//     ds_read_b128.  Two 64-KiB buffers; the tile after next is requested when a tile's MFMAs are done, so a tile has a whole
+//     iteration (MFMAs + epilogue of the tile in front of it) to land.  One counted wait per tile: vmcnt(8) = "everything
+//     but the 8 pieces just requested has arrived" (every wave requests 8 pieces per tile, the last tiles re-request the last one).
+//   * The product is formed TRANSPOSED (W as the A operand, activations as B): a lane then holds four runs of 4 consecutive
+//     outputs of ONE row per 32 x 32 tile (8-byte LDS stores).  The result tile is staged in the buffer its input has just left
+//     (XOR-swizzled 16-byte chunks) and leaves in 512-byte rows, the ReLU mask read the same way (the first build stored 8 bytes
+//     per lane straight from the registers: forward 82 - 108 us per layer, but dX -- whose mask loads then scatter too -- 140 - 160
+//     against bgemm128_kernel's 130).
+// Epilogue like bgemm128_kernel's: + cin (fp32, GEMM_ACC) + bias, ReLU, zero where the stored post-activation `mask` is <= 0.
+constexpr int LG_ROWS = 128, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = 2 * LG_BUF + 1024;
+__device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, unsigned lds_dst) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
+}
+__global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
+                                                       bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                                       const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lg_smem[];
+    float* bias_l = reinterpret_cast<float*>(lg_smem + 2 * LG_BUF);
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lg_smem;
+    if (t < 256) bias_l[t] = bias ? bias[t] : 0.0f;
+    bf16x8t wf[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8t*>(B + (long long)(32 * wv + li) * ldb + 16 * ks + 8 * kh);
+    const int n_tiles = (M + LG_ROWS - 1) / LG_ROWS;
+    // this wave's 8 of a tile's 64 fragments: f = 8 wv + j = (row tile f >> 4, k-step f & 15)
+    auto request = [&](int tile, int buf) {
+        tile = min(tile, n_tiles - 1);
+        const bf16_t* base = A + (long long)tile * LG_ROWS * lda;         // wave-uniform
+        const int rows_left = M - tile * LG_ROWS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = 8 * wv + j, mt = f >> 4, ks = f & 15;
+            const int row = min(32 * mt + li, rows_left - 1);            // rows past the end re-read the last one (never stored)
+            lg_dma(base, (unsigned)((row * lda + 16 * ks + 8 * kh) * 2), lds0 + buf * LG_BUF + f * 1024);
+        }
+    };
+    int it = 0;
+    request(blockIdx.x, 0);
+    request(blockIdx.x + gridDim.x, 1);
+    asm volatile("" :: "v"(wf[0]), "v"(wf[15]) : "memory");       // (the weight loads are in front of the counted waits below)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        const uint8_t* fb = lg_smem + buf * LG_BUF + lane * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8t*>(fb + (16 * mt + ks) * 1024), acc[mt], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // every wave is done reading the buffer: it becomes the result tile's staging area
+        // registers -> LDS: row m of the tile at m * 512 B, its 16-byte chunk c at slot c ^ (m & 31) (a lane column is 32 rows at one
+        // n: without the swizzle they would share a bank)
+        uint8_t* stage = lg_smem + buf * LG_BUF;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int ml = 32 * mt + li;
+            const long long m = (long long)tile * LG_ROWS + ml;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int n0 = 32 * wv + 8 * qd + 4 * kh;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mt][4 * qd + r];
+                if ((flags & GEMM_ACC) && m < M) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(cin + m * ldcin + n0);
+                    v[0] += c4.x; v[1] += c4.y; v[2] += c4.z; v[3] += c4.w;
+                }
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_l + n0);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                if (flags & GEMM_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                }
+                const unsigned lo = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), hi = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(stage + ml * 512 + (((n0 >> 3) ^ (ml & 31)) << 4) + (n0 & 4) * 2) = make_uint2(lo, hi);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // LDS -> HBM: a thread moves chunk t & 31 of rows (t >> 5) + 16 j -- 512 contiguous bytes per row and half-wave; the ReLU
+        // mask (the stored post-activation the consumer of the result was ReLU'd to) is read in the same pattern
+        {
+            const int ch = t & 31, r0 = t >> 5;
+            auto keep = [](unsigned x, unsigned k) {    // keep where the stored post-activation is > 0: a positive bf16 has its sign bit clear and is not zero
+                const unsigned l = ((k & 0x8000u) == 0u && (k & 0x7fffu) != 0u) ? 0xffffu : 0u;
+                const unsigned h = ((k & 0x80000000u) == 0u && (k & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+                return x & (l | h);
+            };
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {            // (two groups of four rows: the masks of a group are in flight together)
+                uint4 kk[4];
+                if (mask) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const long long m = (long long)tile * LG_ROWS + r0 + 16 * (4 * jh + j);
+                        kk[j] = m < M ? *reinterpret_cast<const uint4*>(mask + m * ldm + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ml = r0 + 16 * (4 * jh + j);
+                    const long long m = (long long)tile * LG_ROWS + ml;
+                    uint4 v = *reinterpret_cast<const uint4*>(stage + ml * 512 + ((ch ^ (ml & 31)) << 4));
+                    if (mask) v = make_uint4(keep(v.x, kk[j].x), keep(v.y, kk[j].y), keep(v.z, kk[j].z), keep(v.w, kk[j].w));
+                    if (m < M) *reinterpret_cast<uint4*>(C + m * ldc + ch * 8) = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // the staging area has been read: the next request may overwrite it
+        asm volatile("" ::: "memory");
+        request(tile + 2 * (int)gridDim.x, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA in flight when the wave exits
+}
+
 // ---- the heads' skinny products (alpha: 1 output on 256 inputs, rgb: 3 on 128): one pass over the activations at memory
 // speed instead of a 64-wide GEMM tile with 1-3 useful columns.  XT = the activations' element type; a row of K elements is
 // read by LPR = K / VEC lanes, 16 bytes each (VEC = 8 bf16 or 4 floats).
@@ -826,6 +962,23 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
     bool big = M >= 64 && N >= 64 && aligned(A, a_kcont ? sam : sak, abf) && aligned(B, b_kcont ? sbn : sbk, bbf) &&
                (a_kcont ? K % qa == 0 : M % qa == 0) && (b_kcont ? K % qb == 0 : N % qb == 0);
     if ((abf || bbf) && !t.bf16) return pg_fail(h, PG_EINVAL, "bf16 GEMM operands outside the 16-bit mode");
+    // a 256 x 256 layer of the 16-bit mode (forward / dX of the trunk's plain layers, feature_linear): the persistent kernel
+    static const bool lg_on = [] { const char* e = std::getenv("POSEGEN_LGEMM"); return !(e && e[0] == '0'); }();
+    if (lg_on && big && t.bf16 && abf && bbf && (dt & DT_C) && a_kcont && b_kcont && N == 256 && K == 256 && !seg2 && ksplit == 1 && !rowsum &&
+        sak == 1 && sbk == 1 && ldc % 8 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
+        (!mask || ((dt & DT_M) && ldm % 8 == 0 && reinterpret_cast<uintptr_t>(mask) % 16 == 0)) &&
+        (!(flags & GEMM_ACC) || (ldcin % 4 == 0 && reinterpret_cast<uintptr_t>(cin) % 16 == 0))) {
+        static std::atomic<unsigned long long> attr_done{0};       // the opt-in to > 64 KiB of dynamic LDS is per (kernel, device)
+        if (!(attr_done.load(std::memory_order_acquire) & (1ull << (h->device & 63)))) {
+            PG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lgemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LG_LDS));
+            attr_done.fetch_or(1ull << (h->device & 63), std::memory_order_release);
+        }
+        const int tiles = (M + LG_ROWS - 1) / LG_ROWS;
+        hipLaunchKernelGGL(lgemm256_kernel, dim3(std::min(tiles, h->n_cu)), dim3(512), LG_LDS, s, M, static_cast<const bf16_t*>(A), sam,
+                           static_cast<const bf16_t*>(B), sbn, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin);
+        PG_LAUNCH_CHECK(h, "lgemm256");
+        return PG_OK;
+    }
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
         if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
