@@ -279,17 +279,19 @@ def test_record_kernels_on_odd_ray_and_sample_counts(prec, bound):
     print(f"{prec}: worst |error| vs the fp32 kernel over the odd shapes, both forms {worst:.2e}")
 
 
+@pytest.mark.parametrize("fc", [False, True])
 @pytest.mark.parametrize("prec", ["bf16", "fp16c", "fp32"])
-def test_per_ray_poses_equal_the_per_pose_calls(prec):
+def test_per_ray_poses_equal_the_per_pose_calls(prec, fc):
     """Per-ray skeleton transforms (skts [n,24,4,4], the layout the reference expands them to before the call,
     raycasters.py:361-380): rays of two poses in ONE call, interleaved in blocks of 100, give bitwise what each pose's
     own call gives (fp32) or the same up to the limb masks' sub-2^-24 products (16-bit and compensated modes) -- the kernels
-    read the pose of the ray, not of the call."""
+    read the pose of the ray, not of the call.  fc: the same with frame codes and a code index per ray (h36m's network at 64
+    samples per ray: the on-chip 16x16x32 kernel with a pose AND a code per ray, pg_evalc2.hip<FC, PP>)."""
     prec = prec if isinstance(prec, str) else str(prec)
     from bench import full_frame_rays
     from posegen_amd import PREC_BY_NAME, surreal_config, synthetic as syn
     from posegen_amd.raycaster import HipRayCaster
-    cfg = surreal_config()
+    cfg = h36m_config(n_samples=64) if fc else surreal_config()
     c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 1), device=DEV, precision=prec)
     r = c.renderer
     rb, skts_a, cyl, *_ = full_frame_rays(128, 128, torch.device(DEV))
@@ -299,10 +301,18 @@ def test_per_ray_poses_equal_the_per_pose_calls(prec):
     x = rb[4000:4000 + n].contiguous()
     which = (torch.arange(n, device=DEV) // 100) % 2 == 1
     per_ray = torch.where(which[:, None, None, None], skts_b.expand(n, -1, -1, -1), skts_a.expand(n, -1, -1, -1)).contiguous()
+    cams = ((torch.arange(n, device=DEV) * 7) % cfg.n_framecodes).float() if fc else None
+    if fc:
+        cams[3::11] = -1.0          # (some rays on the mean code)
     try:
-        both = r.render_rays(x, per_ray, cyl, n_samples=64, n_importance=16, want_alpha=False)
-        one_a = r.render_rays(x, skts_a, cyl, n_samples=64, n_importance=16, want_alpha=False)
-        one_b = r.render_rays(x, skts_b, cyl, n_samples=64, n_importance=16, want_alpha=False)
+        r.profile_enable(True)
+        r.profile_read_aux()
+        both = r.render_rays(x, per_ray, cyl, cams=cams, n_samples=64, n_importance=16, want_alpha=False)
+        torch.cuda.synchronize()
+        assert r.profile_read_aux()[0] == 0 or prec == "fp32", "a per-ray-pose call at 64 samples per ray needs no per-ray records"
+        r.profile_enable(False)
+        one_a = r.render_rays(x, skts_a, cyl, cams=cams, n_samples=64, n_importance=16, want_alpha=False)
+        one_b = r.render_rays(x, skts_b, cyl, cams=cams, n_samples=64, n_importance=16, want_alpha=False)
     finally:
         r.close()
     # Since round 5 a per-ray-pose call runs the same record-free kernels as a one-pose call (the 16x16x32 kernel's on-chip
