@@ -254,7 +254,7 @@ def test_render_rays_vs_reference_golden(casters, name, prec):
 
 @pytest.mark.parametrize("form,env", [
     ("record forms of the 16x16x32 kernel and of pg_evalc.hip", {"POSEGEN_ONCHIP": "0", "POSEGEN_EVALC2": "0"}),
-    ("default forms of the 16x16x32 kernel and of pg_evalc.hip", {"POSEGEN_EVALC2": "0"}),
+    ("default forms of the 16x16x32 kernel and of pg_evalc.hip", {"POSEGEN_EVALC2": "0", "POSEGEN_ONCHIP": "1"}),
     ("on-chip forms whatever the sample count", {"POSEGEN_ONCHIP": "2", "POSEGEN_EVALC2": "0"})])
 def test_other_kernel_forms_vs_reference_golden(form, env):
     """every form of the fused kernels is pinned to the REFERENCE's vectors directly, not through another
