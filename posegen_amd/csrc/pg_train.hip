@@ -724,6 +724,48 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const XT* __restrict__ X
     }
 }
 
+// dX[p][k] = sum_{o < NO} dY[p][o] W[o][k] (the heads' input gradients: 1 or 3 products per element), eight columns per thread,
+// zeroed where the stored post-activation `relu_of` (element type of dX) is <= 0: one pass that writes dX at memory speed
+// instead of a 64-wide GEMM tile with K = 1..3 and a masking kernel behind it (33 - 103 + 37 us per call)
+template <typename CT, int NO>
+__global__ __launch_bounds__(256) void skinny_bwd_x_kernel(const float* __restrict__ dY, long long ldy, long long P, int K, const float* __restrict__ Wt, long long ldw,
+                                                           CT* __restrict__ dX, long long ldx, const CT* __restrict__ relu_of) {
+    const int tpr = K / 8;                      // threads per row
+    const long long i = blockIdx.x * 256ll + threadIdx.x, p = i / tpr;
+    const int k0 = (int)(i - p * tpr) * 8;
+    if (p >= P) return;
+    float g[NO], v[8];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) g[o] = dY[p * ldy + o];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float s = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) s = fmaf(g[o], Wt[o * ldw + k0 + e], s);
+        v[e] = s;
+    }
+    if (relu_of) {
+        CT hk[8];           // (one or two 16-byte loads)
+        if constexpr (sizeof(CT) == 2) *reinterpret_cast<uint4*>(hk) = *reinterpret_cast<const uint4*>(relu_of + p * ldx + k0);
+        else { *reinterpret_cast<float4*>(hk) = *reinterpret_cast<const float4*>(relu_of + p * ldx + k0); *reinterpret_cast<float4*>(hk + 4) = *reinterpret_cast<const float4*>(relu_of + p * ldx + k0 + 4); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float hv;
+            if constexpr (sizeof(CT) == 2) hv = bf2f(hk[e]); else hv = hk[e];
+            if (!(hv > 0.0f)) v[e] = 0.0f;
+        }
+    }
+    if constexpr (sizeof(CT) == 2) {
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(dX + p * ldx + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        *reinterpret_cast<float4*>(dX + p * ldx + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dX + p * ldx + k0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // out[i (row-major M x N with leading dimension ldo)] = sum over the nz slices of part[z][M][N], in slice order
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nz, int M, int N,
                                                           float* __restrict__ out, long long ldo) {
@@ -787,9 +829,33 @@ __global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict
         if (c0 + i < cols && r0 + tx < rows) dst[(long long)(c0 + i) * rows + r0 + tx] = f2bf(tile[tx][i]);
 }
 
-// part[block][n] = sum over the block's 256 rows of d[row * ld + n] (bias gradients; reduce_parts_kernel adds the
-// blocks in order)
+// part[block][n] = sum over the block's CS_ROWS rows of d[row * ld + n], N <= 4 (the heads' bias gradients: columns of d_raw;
+// reduce_parts_kernel adds the blocks in order).  Thread t adds rows r0 + t, r0 + t + 256, .. in that order, the 256 shares are
+// added by a fixed tree: bitwise repeatable.  (Until round 5 a block covered 256 rows with ONE thread per column -- 1 to 3 active
+// threads per block -- and left 1280 slices to a single reduction block: 70 - 105 us per call, 0.5 ms per step.)
+constexpr int CS_ROWS = 4096;
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part, int bf) {
+    __shared__ float red[4][256];
+    const long long r0 = (long long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long r = r0 + threadIdx.x; r < r1; r += 256)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < N) s[n] += ld_el(d, r * ld + n, bf);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) red[n][threadIdx.x] = s[n];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) red[n][threadIdx.x] += red[n][threadIdx.x + w];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < N) part[(long long)blockIdx.x * N + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// the same for any number of columns, a thread per column over the block's 256 rows (the row sums behind a small-tile GEMM)
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const void* __restrict__ d, long long rows, int N, long long ld, float* __restrict__ part, int bf) {
     const long long r0 = blockIdx.x * 256ll, r1 = min(rows, r0 + 256);
     for (int n = threadIdx.x; n < N; n += 256) {
         float s = 0.0f;
@@ -1036,7 +1102,7 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
     if (rowsum) {
         const unsigned blocks = (unsigned)((K + 255) / 256);
         if ((size_t)blocks * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
-        hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, A, (long long)K, M, sak, t.rs_part, abf ? 1 : 0);
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3(blocks), dim3(256), 0, s, A, (long long)K, M, sak, t.rs_part, abf ? 1 : 0);
         PG_LAUNCH_CHECK(h, "colsum");
         reduce(t.rs_part, (int)blocks, 1, M, rowsum, M);
         PG_LAUNCH_CHECK(h, "column-sum reduction");
@@ -1078,6 +1144,20 @@ int linear_fwd2(pg_handle* h, hipStream_t s, long long P, int out, int in1, cons
 int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* dY, long long ldy, const void* W, long long ldw,
                  void* dX, long long ldx, int flags, const void* relu_of = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0,
                  const bf16_t* WT = nullptr) {
+    // the heads (1 or 3 outputs, fp32 dY and weights): one pass that writes dX
+    if ((out == 1 || out == 3) && !WT && flags == 0 && !(dt & (DT_A | DT_B)) && in % 8 == 0 && ldx % 8 == 0 && reinterpret_cast<uintptr_t>(dX) % 16 == 0 &&
+        (!relu_of || reinterpret_cast<uintptr_t>(relu_of) % 16 == 0) &&
+        (!relu_of || ((dt & DT_M) != 0) == ((dt & DT_C) != 0))) {
+        const unsigned grid = (unsigned)((P * (in / 8) + 255) / 256);
+        const float* dYf = static_cast<const float*>(dY);
+        const float* Wf = static_cast<const float*>(W);
+#define PG_SKX(CT, NO) hipLaunchKernelGGL((skinny_bwd_x_kernel<CT, NO>), dim3(grid), dim3(256), 0, s, dYf, ldy, P, in, Wf, ldw, static_cast<CT*>(dX), ldx, static_cast<const CT*>(relu_of))
+        if (dt & DT_C) { if (out == 1) PG_SKX(bf16_t, 1); else PG_SKX(bf16_t, 3); }
+        else { if (out == 1) PG_SKX(float, 1); else PG_SKX(float, 3); }
+#undef PG_SKX
+        PG_LAUNCH_CHECK(h, "skinny input gradient");
+        return PG_OK;
+    }
     // WT: the step's transposed bf16 copy [in][out] of W's block -- both operands k-contiguous (16-byte tile stores, no transposing ones)
     if (WT) return gemm(h, s, true, true, (int)P, in, out, dY, ldy, 1, WT, 1, out, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
     return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
@@ -1115,7 +1195,8 @@ int linear_bwd_w(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
 }
 int colsum(pg_handle* h, hipStream_t s, const float* d, long long rows, int N, long long ld, float* out) {
     Tape& t = *tape_of(h);
-    const unsigned blocks = (unsigned)((rows + 255) / 256);
+    if (N > 4) return pg_fail(h, PG_EINVAL, "colsum: at most 4 columns (the heads' bias gradients)");
+    const unsigned blocks = (unsigned)((rows + CS_ROWS - 1) / CS_ROWS);
     if ((size_t)blocks * N > RS_FLOATS) return pg_fail(h, PG_EINVAL, "column-sum scratch too small");
     hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, d, rows, N, ld, t.rs_part, 0);
     PG_LAUNCH_CHECK(h, "colsum");
@@ -1184,10 +1265,9 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
     const float* d_raw = t.d_raw;
     void* dG = t.dG;
     // rgb_linear: raw[:, :3] = G Wr^T + br
-    PG_TRY(linear_bwd_x(h, s, P, 3, VW, d_raw, 4, w.w[22], VW, dG, VW, 0, nullptr, C_));
+    PG_TRY(linear_bwd_x(h, s, P, 3, VW, d_raw, 4, w.w[22], VW, dG, VW, 0, p.G, bf ? (DT_C | DT_M) : 0));       // (masked by [G > 0] in the same pass)
     PG_TRY(linear_bwd_w(h, s, P, 3, VW, d_raw, 4, p.G, VW, g.w[22], VW, nullptr, B_));
     PG_TRY(colsum(h, s, d_raw, P, 3, 4, g.w[23]));
-    PG_TRY(relu_mask(h, s, dG, p.G, P * VW, bf));
     // views_linears.0 on [feature | view embedding (| frame code)]
     PG_TRY(linear_bwd_w(h, s, P, VW, W, dG, VW, p.F, W, g.w[20], vcols, g.w[21], AB));
     PG_TRY(linear_bwd_w(h, s, P, VW, vk, dG, VW, el_off(p.X, CH_X, es), XW, g.w[20] + W, vcols, nullptr, AB));
