@@ -289,11 +289,22 @@ def train_step_rate(dev, n_rand=4096, steps=5, warmup=2, precision="fp32"):
     ms = (time.perf_counter() - t0) * 1e3 / steps
     pts = n_rand * (2 * cfg.n_samples + cfg.n_importance)
     flop = 3.0 * pts * cfg.flops_per_point()
+    # parameters -> the fused inference kernels' packed weights (what a validation render between optimiser steps needs)
+    sync = {}
+    for route, on_dev in (("device", True), ("host", False)):
+        m.sync_inference_weights(on_device=on_dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            m.sync_inference_weights(on_device=on_dev)
+        torch.cuda.synchronize()
+        sync[route] = (time.perf_counter() - t1) * 1e3 / 5
     m.renderer.close()
     peak = PEAK_TFLOPS["fp32" if precision == "fp32" else "bf16"]
     return {"n_rand": n_rand, "ms_per_step": ms, "rays_per_s": n_rand / (ms * 1e-3), "points_per_step": pts,
             "gemm_flop_per_step": flop, "tflops": flop / (ms * 1e-3) / 1e12, "peak_tflops": peak,
             "frac": flop / (ms * 1e-3) / 1e12 / peak, "dtype": "f32" if precision == "fp32" else "bf16", "loss": float(loss.detach()),
+            "sync_inference_weights_ms": sync["device"], "sync_inference_weights_host_route_ms": sync["host"],
             "what": "forward with a tape + MSE loss + loss.backward() + Adam on the whole step's wall clock, "
                     + ("fp32 (v_mfma_f32_32x32x2_f32 GEMMs)" if precision == "fp32" else
                        "16-bit training mode (the tape -- embedding rows, activations, their gradients -- stored in bf16, bf16 operands in the large GEMMs on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights, raw, d_raw and weight gradients fp32)")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 9
+#define PG_ABI_VERSION 10
 
 /* error codes */
 #define PG_OK 0
@@ -380,6 +380,15 @@ int pg_stage_composite(pg_handle* h, void* stream, int64_t n, int n_samples,
  * cutoff_dist + 24 / (tau log2 e) has a cutoff weight 1 - sigmoid(tau (v - c)) below 2^-24, cutoff_embedder.py:139-146:
  * DESIGN.md 2.1).  Default on.  The two settings agree to ~1e-7 per skipped product. */
 int pg_set_far_skip(pg_handle* h, int on);
+
+/* New values of a loaded net's 24 tensors (pg_load_weights order, fp32, DEVICE pointers; and of the frame codes [n_codes,16]
+ * when the handle has them) between optimiser steps and a render -- the reference renders with the module it trains
+ * (core/trainer.py:463); here the fused kernels' packed weight images follow the parameters.  The images of the fast paths
+ * are re-formed on the device, bitwise as pg_load_weights would pack them; every other image is re-packed from refreshed host
+ * copies by the first call that needs it.  Needs a prior pg_load_weights (and pg_set_framecodes) of the net; single-device
+ * handles only.  Enqueued on `stream`. */
+int pg_load_weights_device(pg_handle* h, void* stream, int which_net, const float* const* d_tensors, int n_tensors,
+                           const float* d_codes, int n_codes);
 
 /* Which form of the fused 16-bit kernel (pg_eval16r.hip) calls with >= 64 samples per ray take -- both compute
  * encode_inputs + NeRF.forward (core/raycasters.py:476-577, core/networks/nerf.py:90-148), they differ in where the

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libposegen_hip.so")
 PG_OK, PG_EINVAL, PG_ENOMEM, PG_EHIP, PG_ESTATE = 0, -1, -2, -3, -4
 PG_FLAG_LINDISP = 1
 PG_ACT_RELU, PG_ACT_SOFTPLUS = 0, 1
-PG_ABI_VERSION = 9
+PG_ABI_VERSION = 10
 
 
 class HipLibraryError(RuntimeError):
@@ -76,6 +76,7 @@ PROTOTYPES = {
     "pg_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_set_far_skip": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_set_onchip": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_load_weights_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int]),
     "pg_set_train_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _FP, _FP, C.c_int64, _FP, C.c_int64, _FP,
                                  C.c_int, C.c_int, C.c_int, C.POINTER(PgOutputs)]),

@@ -62,6 +62,14 @@ int pg_launch_pose_boxes(const float* kps, long long n, const double* w2c, long 
 int pg_launch_frame_compose(const pgk::FrameGeom* g, const float* rgb_map, const float* disp_map, const float* acc_map,
                             const float* bg, float base_bg, float* rgb, float* disp, float* acc, uint8_t* rgb8,
                             void* stream);
+// pg_repack.hip: packed images re-formed on the device (pg_load_weights_device)
+void pg_launch_collect(const float* const* tensors, const long long* off25, float* dst, void* stream);
+void pg_launch_fold(float* src, long long off_view_w, int vcols, long long off_view_b, long long off_feat_w, long long off_feat_b,
+                    long long off_fw, long long off_fb, void* stream);
+void pg_launch_gather16(const int32_t* map, const float* src, uint16_t* out, long long n, int is_bf, void* stream);
+void pg_launch_gather32(const int32_t* map, const float* src, float* out, long long n, void* stream);
+void pg_launch_codes(const float* codes, int n_codes, float* out, void* stream);
+void pg_launch_ycode(const float* view_w, int vcols, const float* codes, int n_codes, float* yc, void* stream);
 }
 
 namespace {
@@ -125,6 +133,27 @@ pgpack::NetTensors tensors_of(const NetState& ns, const pg_config& cfg) {
     return t;
 }
 
+// ... of a handle's net: first the host copies are brought up to date if the last weights came from the device
+// (pg_load_weights_device leaves them stale: only the images it re-forms itself are current)
+int refresh_host(pg_handle* h, NetState& ns) {
+    if (!ns.host_stale) return PG_OK;
+    pgpack::NetTensors lay;
+    lay.layout(h->cfg.framecode_ch);
+    PG_HIP(h, hipSetDevice(h->device));
+    PG_HIP(h, hipDeviceSynchronize());
+    for (int i = 0; i < 24; ++i)
+        PG_HIP(h, hipMemcpy(ns.host[i].data(), ns.d_src + lay.off[i], ns.host[i].size() * sizeof(float), hipMemcpyDeviceToHost));
+    ns.fold_w.clear(); ns.fold_b.clear();
+    if (ns.d_codes && !ns.codes_host.empty())
+        PG_HIP(h, hipMemcpy(ns.codes_host.data(), ns.d_codes, ns.codes_host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    ns.host_stale = false;
+    std::vector<float> bias;
+    pgpack::pack_bias(tensors_of(ns, h->cfg), bias);
+    if (!ns.d_bias) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_bias), BIAS_FLOATS * sizeof(float)));
+    PG_HIP(h, hipMemcpy(ns.d_bias, bias.data(), BIAS_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
 // The 16-bit precisions factorise the view layer over rays when a pass cannot touch more than MAXR_F rays
 // (pg_layout.h): per-ray records (pg_rayrec.hip) + the 16x16x32 kernel (pg_eval16r.hip); POSEGEN_VIEW_FACT=0
 // forces the direct 32x32x16 kernel (pg_eval16.hip) everywhere (A/B, debugging).
@@ -165,6 +194,7 @@ int ensure_stream_r(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream_r[prec] && ns.d_bias_s && ns.d_vy[prec]) return PG_OK;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const pgpack::NetTensors t = tensors_of(ns, h->cfg);        // (folds feature_linear into the view layer: milliseconds of host work)
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_stream_r[prec]) {
@@ -195,6 +225,7 @@ int ensure_stream_ro(pg_handle* h, int which, int prec) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream_ro[prec] && ns.d_bias_s) return PG_OK;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const pgpack::NetTensors t = tensors_of(ns, h->cfg);
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_stream_ro[prec]) {
@@ -238,6 +269,7 @@ int ensure_ycode(pg_handle* h, int which) {
     NetState& ns = h->net[which];
     if (ns.d_ycode) return PG_OK;
     if (!ns.loaded || ns.codes_host.empty()) return pg_fail(h, PG_ESTATE, "frame codes of net %d not set (pg_set_framecodes)", which);
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const int vcols = W + CH_D + FC_CH;
     const std::vector<float>& wv = ns.host[20];
     std::vector<float> yc((size_t)(ns.n_codes + 1) * VW);
@@ -257,6 +289,7 @@ int ensure_stream_cr(pg_handle* h, int which) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream_cr && ns.d_vyc) return PG_OK;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const pgpack::NetTensors t = tensors_of(ns, h->cfg);
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_stream_cr) {
@@ -281,6 +314,7 @@ int ensure_stream_co(pg_handle* h, int which) {
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream_co) return PG_OK;
     std::vector<uint8_t> packed;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), PG_PREC_FP16C, false, true, packed, nullptr, true, true);
     if (rc != 0) return pg_fail(h, PG_EINVAL, "compensated-fp16 on-chip stream packing failed (%d)", rc);
     PG_HIP(h, hipSetDevice(h->device));
@@ -302,6 +336,7 @@ int ensure_c2(pg_handle* h, int which) {
     NetState& ns = h->net[which];
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_c2 && ns.d_bias_s) return PG_OK;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const pgpack::NetTensors t = tensors_of(ns, h->cfg);
     PG_HIP(h, hipSetDevice(h->device));
     if (!ns.d_c2) {
@@ -325,6 +360,7 @@ int ensure_stream(pg_handle* h, int which, int prec, bool fact) {
     if (!ns.loaded) return pg_fail(h, PG_ESTATE, "weights of net %d not loaded", which);
     if (ns.d_stream[prec][fact]) return PG_OK;
     std::vector<uint8_t> packed;
+    if (const int rr_ = refresh_host(h, ns)) return rr_;        // (the last weights may have come from the device)
     const int rc = pgpack::pack_stream(tensors_of(ns, h->cfg), prec, h->cfg.framecode_ch > 0, fact, packed);
     if (rc != 0) return pg_fail(h, PG_EINVAL, "weight stream packing failed (%d) for precision %d", rc, prec);
     PG_HIP(h, hipSetDevice(h->device));
@@ -631,6 +667,10 @@ void pg_destroy(pg_handle* h) {
         if (ns.d_vyc) (void)hipFree(ns.d_vyc);
         if (ns.d_bias) (void)hipFree(ns.d_bias);
         if (ns.d_codes) (void)hipFree(ns.d_codes);
+        if (ns.d_src) (void)hipFree(ns.d_src);
+        if (ns.d_map_ro) (void)hipFree(ns.d_map_ro);
+        if (ns.d_map_c2) (void)hipFree(ns.d_map_c2);
+        if (ns.d_map_bias_s) (void)hipFree(ns.d_map_bias_s);
     }
     for (auto& pr : h->ev_used) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& ev : h->ev_free) (void)hipEventDestroy(ev);
@@ -666,6 +706,7 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     ns.fold_w.clear(); ns.fold_b.clear();
     for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + want[i][0] * want[i][1]);
     ns.loaded = true;
+    ns.host_stale = false;
     PG_HIP(h, hipSetDevice(h->device));
     for (int p = 0; p < PG_PREC_COUNT; ++p)
         for (int f = 0; f < 2; ++f)
@@ -695,6 +736,88 @@ int pg_load_weights(pg_handle* h, int which, const float* const* tensors, const 
     }
     PG_FORWARD(h, pg_load_weights(hh, which, tensors, shapes, n_tensors));
     return PG_OK;
+}
+
+// New values for a loaded net's tensors (and frame codes) from DEVICE memory -- what sits between optimiser steps and a
+// validation render (TrainableRayCaster.sync_inference_weights; the reference renders with the module it trains,
+// core/trainer.py:463).  The images of the fast paths -- the on-chip stream of the 16x16x32 kernel (bf16 / fp16), pg_evalc2.hip's
+// weight image, their bias table, the frame-code tables -- are re-formed on the device, bitwise as pg_load_weights would pack
+// them (pg_repack.hip); every other image is dropped and re-packed from the host copies, which are refreshed from the device,
+// by the first call that needs it.  Enqueued on `stream`; the tensors may be reused as soon as the call returns in stream order.
+int pg_load_weights_device(pg_handle* h, void* stream, int which, const float* const* d_tensors, int n_tensors, const float* d_codes, int n_codes) {
+    if (!h || !d_tensors) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: null argument");
+    if (which < 0 || which > 1) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: which_net must be 0 or 1");
+    if (n_tensors != 24) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: expected 24 tensors, got %d", n_tensors);
+    if (!h->peers.empty()) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: a multi-device handle takes its weights from the host (pg_load_weights)");
+    NetState& ns = h->net[which];
+    if (!ns.loaded) return pg_fail(h, PG_ESTATE, "pg_load_weights_device: net %d has no weights yet (the first load is pg_load_weights: it fixes the shapes)", which);
+    const bool fc = h->cfg.framecode_ch > 0;
+    if (fc && (!d_codes || n_codes != ns.n_codes || !ns.d_codes))
+        return pg_fail(h, PG_EINVAL, "pg_load_weights_device: frame codes [%d,16] expected (set once by pg_set_framecodes)", ns.n_codes);
+    for (int i = 0; i < 24; ++i)
+        if (!d_tensors[i]) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: tensor %d is null", i);
+    PG_HIP(h, hipSetDevice(h->device));
+    pgpack::NetTensors lay;                                 // (offsets only; a source map is built from the shapes, see map_tensors)
+    lay.layout(h->cfg.framecode_ch);
+    auto map_tensors = [&]() {      // the packers in index mode: pointers and shapes as usual, the (possibly stale) values are not what is recorded
+        pgpack::NetTensors t = tensors_of(ns, h->cfg);
+        t.layout(h->cfg.framecode_ch);
+        return t;
+    };
+    if (!ns.d_src) PG_HIP(h, hipMalloc(reinterpret_cast<void**>(&ns.d_src), (size_t)lay.off[pgpack::NetTensors::N_SRC] * sizeof(float)));
+    pg_launch_collect(d_tensors, lay.off, ns.d_src, stream);        // (off[24] = the end of tensor 23: the folded view layer follows)
+    const int vcols = W + CH_D + h->cfg.framecode_ch;
+    pg_launch_fold(ns.d_src, lay.off[20], vcols, lay.off[21], lay.off[18], lay.off[19], lay.off[pgpack::NetTensors::SRC_VIEWF_W],
+                   lay.off[pgpack::NetTensors::SRC_VIEWF_B], stream);
+    auto upload_map = [&](const std::vector<int32_t>& m, int32_t** d, size_t* n) -> int {
+        PG_HIP(h, hipMalloc(reinterpret_cast<void**>(d), m.size() * sizeof(int32_t)));
+        PG_HIP(h, hipMemcpy(*d, m.data(), m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (n) *n = m.size();
+        return PG_OK;
+    };
+    // images re-formed here (those that exist: the others are built by the first call that needs them)
+    bool any_ro = false;
+    for (int prec : {PG_PREC_BF16, PG_PREC_FP16}) any_ro = any_ro || ns.d_stream_ro[prec];
+    if (any_ro && !ns.d_map_ro) {
+        std::vector<uint8_t> img; std::vector<int32_t> m;
+        if (pgpack::pack_stream_r(map_tensors(), PG_PREC_BF16, img, true, &m) != 0) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: source map of the on-chip stream");
+        if (const int rc = upload_map(m, &ns.d_map_ro, &ns.n_map_ro)) return rc;
+    }
+    for (int prec : {PG_PREC_BF16, PG_PREC_FP16})
+        if (ns.d_stream_ro[prec])
+            pg_launch_gather16(ns.d_map_ro, ns.d_src, reinterpret_cast<uint16_t*>(ns.d_stream_ro[prec]), (long long)ns.n_map_ro, prec == PG_PREC_BF16, stream);
+    if (ns.d_c2) {
+        if (!ns.d_map_c2) {
+            std::vector<uint8_t> img; std::vector<int32_t> m;
+            if (pgpack::pack_c2(map_tensors(), fc, img, &m) != 0) return pg_fail(h, PG_EINVAL, "pg_load_weights_device: source map of the tile-split image");
+            if (const int rc = upload_map(m, &ns.d_map_c2, &ns.n_map_c2)) return rc;
+        }
+        pg_launch_gather16(ns.d_map_c2, ns.d_src, reinterpret_cast<uint16_t*>(ns.d_c2), (long long)ns.n_map_c2, 0, stream);
+    }
+    if (ns.d_bias_s) {
+        if (!ns.d_map_bias_s) {
+            std::vector<float> b; std::vector<int32_t> m;
+            pgpack::pack_bias_s(map_tensors(), b, &m);
+            if (const int rc = upload_map(m, &ns.d_map_bias_s, nullptr)) return rc;
+        }
+        pg_launch_gather32(ns.d_map_bias_s, ns.d_src, ns.d_bias_s, (long long)BIAS16_FLOATS, stream);
+    }
+    if (fc) {
+        pg_launch_codes(d_codes, ns.n_codes, ns.d_codes, stream);
+        if (ns.d_ycode) pg_launch_ycode(ns.d_src + lay.off[20], vcols, ns.d_codes, ns.n_codes, ns.d_ycode, stream);
+    }
+    PG_HIP(h, hipGetLastError());
+    // everything else: dropped (hipFree waits for the device: only forms the run has used beside the fast paths pay it)
+    auto drop = [&](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    for (int p = 0; p < PG_PREC_COUNT; ++p) {
+        for (int f = 0; f < 2; ++f) drop(ns.d_stream[p][f]);
+        drop(ns.d_vy[p]); drop(ns.d_stream_r[p]);
+        if (p != PG_PREC_BF16 && p != PG_PREC_FP16) drop(ns.d_stream_ro[p]);
+    }
+    drop(ns.d_stream_cr); drop(ns.d_stream_co); drop(ns.d_vyc);
+    ns.fold_w.clear(); ns.fold_b.clear();
+    ns.host_stale = true;               // (refresh_host also re-forms d_bias, the bias table of the other kernels)
+    return ensure_mode_streams(h, which, h->cfg.precision);
 }
 
 int pg_set_embedder(pg_handle* h, int which, const float* cutoff_dist, float tau) {

@@ -28,6 +28,13 @@ struct NetState {
     size_t stream_bytes[PG_PREC_COUNT][2] = {};
     float* d_bias = nullptr;
     float* d_codes = nullptr;
+    // pg_load_weights_device: the net's tensors as one flat device vector (NetTensors::layout; + the folded view layer), the
+    // source maps of the images that are re-formed by a gather, and whether `host` lags the device copy
+    float* d_src = nullptr;
+    int32_t* d_map_ro = nullptr;   size_t n_map_ro = 0;      // on-chip stream of the 16x16x32 kernel (one map for bf16 and fp16)
+    int32_t* d_map_c2 = nullptr;   size_t n_map_c2 = 0;      // pg_evalc2.hip's weight image
+    int32_t* d_map_bias_s = nullptr;
+    bool host_stale = false;
 };
 
 

@@ -78,6 +78,42 @@ float NetTensors::w(int mat, int row, int col) const {
     return p[(size_t)row * cols + col];
 }
 
+void NetTensors::layout(int framecode_ch) {
+    long long o = 0;
+    for (int l = 0; l < DEPTH; ++l) {
+        const int cols = l == 0 ? CH_X : (l == SKIP + 1 ? CH_X + W : W);
+        off[2 * l] = o; o += (long long)W * cols;
+        off[2 * l + 1] = o; o += W;
+    }
+    off[16] = o; o += W;            off[17] = o; o += 1;
+    off[18] = o; o += (long long)W * W;    off[19] = o; o += W;
+    off[20] = o; o += (long long)VW * (W + CH_D + framecode_ch);   off[21] = o; o += VW;
+    off[22] = o; o += 3 * VW;       off[23] = o; o += 3;
+    off[SRC_VIEWF_W] = o; o += (long long)VW * W;
+    off[SRC_VIEWF_B] = o; o += VW;
+    off[N_SRC] = o;
+}
+
+long long NetTensors::flat(int mat, int row, int col) const {
+    int id = -1, rows = 0, cols = 0;
+    if (mat >= MAT_L0 && mat < MAT_L0 + DEPTH) { id = 2 * mat; rows = W; cols = lcols[mat]; }
+    else if (mat == MAT_FEAT) { id = 18; rows = W; cols = W; }
+    else if (mat == MAT_ALPHA) { id = 16; rows = 1; cols = W; }
+    else if (mat == MAT_VIEW) { id = 20; rows = VW; cols = view_cols; }
+    else if (mat == MAT_RGB) { id = 22; rows = 3; cols = VW; }
+    else if (mat == MAT_VIEWF) { id = SRC_VIEWF_W; rows = VW; cols = W; }
+    else if (mat == MAT_ALPHA_VIEWF) {
+        if (row < 32) { id = 16; rows = 1; cols = W; }
+        else { id = SRC_VIEWF_W; rows = VW; cols = W; row -= 32; }
+    }
+    else if (mat == MAT_FEAT_ALPHA) {
+        if (row < W) { id = 18; rows = W; cols = W; }
+        else { id = 16; rows = 1; cols = W; row -= W; }
+    }
+    if (id < 0 || row < 0 || row >= rows || col < 0 || col >= cols) return -1;
+    return off[id] + (long long)row * cols + col;
+}
+
 // feature = W_f h + b_f enters the view layer linearly (no activation in between), so
 // W_view[:, :256] feature = (W_view[:, :256] W_f) h + W_view[:, :256] b_f.  Products in double.
 void NetTensors::fold() {
@@ -267,8 +303,11 @@ int pack_vy(const NetTensors& t, int precision, bool fc, std::vector<uint8_t>& o
 
 // ---- 16x16x32 kernel (pg_eval16r.hip): units are 16 out rows x 32 k; lane (g, row) holds k = 32u + 8g + 0..7.
 // Segments start on chunk boundaries, except the rgb head, which follows the alpha / view tiles directly. ----
-int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out, bool onchip) {
+static inline int32_t src_entry(long long flat, int kind) { return flat < 0 ? -1 : (int32_t)((flat << 2) | kind); }
+
+int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out, bool onchip, std::vector<int32_t>* src) {
     if (precision != PG_PREC_BF16 && precision != PG_PREC_FP16) return -3;
+    if (src) src->clear();
     if (t.viewf_w.size() != (size_t)VW * W) return -4;
     const bool is_bf = precision == PG_PREC_BF16;
     struct Seg { int mat, no, nu; bool kmajor, xseq; int colbase; bool pad; };
@@ -297,6 +336,7 @@ int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out,
                                 const float wv = t.w(MAT_VIEW, 16 * tt + (lane & 15), W + ch);
                                 const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
                                 std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                                if (src) { src->resize(out.size() / 2, -1); (*src)[(base + lane * 16 + e * 2) / 2] = src_entry(t.flat(MAT_VIEW, 16 * tt + (lane & 15), W + ch), SRC_PLAIN); }
                             }
                     }
             continue;
@@ -318,30 +358,37 @@ int pack_stream_r(const NetTensors& t, int precision, std::vector<uint8_t>& out,
                     const float wv = t.w(sg.mat, wrow, sg.colbase + ch);
                     const uint16_t hi = is_bf ? f32_to_bf16(wv) : f32_to_f16(wv);
                     std::memcpy(&out[base + lane * 16 + e * 2], &hi, 2);
+                    if (src) { src->resize(out.size() / 2, -1); (*src)[(base + lane * 16 + e * 2) / 2] = src_entry(t.flat(sg.mat, wrow, sg.colbase + ch), SRC_PLAIN); }
                 }
             }
         }
         if (sg.pad) out.resize((out.size() + CHUNK_BYTES - 1) / CHUNK_BYTES * CHUNK_BYTES, 0);
     }
+    if (src) src->resize(out.size() / 2, -1);
     return out.size() == (size_t)(onchip ? R::NCHUNK_OC : R::NCHUNK) * CHUNK_BYTES ? 0 : -2;
 }
 
 // ---- compensated kernel with the out tiles split over the waves (pg_evalc2.hip, pg_program.h T): no stream, one
 // 4-KiB block of four A fragments per (k-unit, wave): [tile t of the wave][plane], lane (g, row): k = 8 g + e ----
-int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out) {
+int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out, std::vector<int32_t>* src) {
     if (t.viewf_w.size() != (size_t)VW * W) return -4;
     out.assign((size_t)T::TOTAL, 0);
+    if (src) src->assign((size_t)T::TOTAL / 2, -1);
     auto comp_pair = [](float wv, uint16_t& p0, uint16_t& p1) {
         const double wd = (double)wv / COMP_S;
         const double w1 = f16_to_f32(f32_to_f16((float)wd));
         p0 = f32_to_f16((float)((COMP_S - 1) * w1));
         p1 = f32_to_f16((float)(w1 + COMP_S * (wd - w1)));
     };
-    auto put = [&](size_t frag0, int lane, int e, float wv) {       // planes at frag0 and frag0 + FRAG
+    auto put = [&](size_t frag0, int lane, int e, int mat, int row, int col) {       // planes at frag0 and frag0 + FRAG
         uint16_t p0, p1;
-        comp_pair(wv, p0, p1);
+        comp_pair(t.w(mat, row, col), p0, p1);
         std::memcpy(&out[frag0 + lane * 16 + e * 2], &p0, 2);
         std::memcpy(&out[frag0 + T::FRAG + lane * 16 + e * 2], &p1, 2);
+        if (src) {
+            (*src)[(frag0 + lane * 16 + e * 2) / 2] = src_entry(t.flat(mat, row, col), SRC_COMP0);
+            (*src)[(frag0 + T::FRAG + lane * 16 + e * 2) / 2] = src_entry(t.flat(mat, row, col), SRC_COMP1);
+        }
     };
     // trunk sections: `xseq` = the density input in X16 order, else the previous activation (hseq16_channel) at column `colbase`
     auto trunk = [&](size_t off, int mat, int nu, bool xseq, int colbase) {
@@ -354,7 +401,7 @@ int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out) {
                             const int g = lane >> 4, row = lane & 15;
                             const int ch = xseq ? xseq16_channel(8 * u + e, g) : hseq16_channel(8 * u + e, g);
                             if (ch < 0) continue;
-                            put(f0, lane, e, t.w(mat, 16 * (2 * w + tt) + row, colbase + ch));
+                            put(f0, lane, e, mat, 16 * (2 * w + tt) + row, colbase + ch);
                         }
                 }
     };
@@ -367,7 +414,7 @@ int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out) {
                 const size_t f0 = T::OFF_AV + ((size_t)(u * 4 + v) * 4 + tt * 2) * T::FRAG;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e)
-                        put(f0, lane, e, t.w(MAT_VIEWF, 16 * (2 * v + tt) + (lane & 15), hseq16_channel(8 * u + e, lane >> 4)));
+                        put(f0, lane, e, MAT_VIEWF, 16 * (2 * v + tt) + (lane & 15), hseq16_channel(8 * u + e, lane >> 4));
             }
     for (int s = 0; s < J + (fc ? 1 : 0); ++s)          // direction part: B fragments [slot][out tile16]
         for (int tt = 0; tt < NTV16; ++tt) {
@@ -377,42 +424,48 @@ int pack_c2(const NetTensors& t, bool fc, std::vector<uint8_t>& out) {
                 for (int e = 0; e < 8; ++e) {
                     const int ch = vd_channel(j, 8 * (lane >> 4) + e);
                     if (ch < 0) continue;
-                    put(f0, lane, e, t.w(MAT_VIEW, 16 * tt + (lane & 15), W + ch));
+                    put(f0, lane, e, MAT_VIEW, 16 * tt + (lane & 15), W + ch);
                 }
         }
-    auto put_small = [&](size_t base, size_t plane_stride, int e, float wv) {
+    auto put_small = [&](size_t base, size_t plane_stride, int e, int mat, int row, int col) {
         uint16_t p0, p1;
-        comp_pair(wv, p0, p1);
+        comp_pair(t.w(mat, row, col), p0, p1);
         std::memcpy(&out[base + e * 2], &p0, 2);
         std::memcpy(&out[base + plane_stride + e * 2], &p1, 2);
+        if (src) {
+            (*src)[(base + e * 2) / 2] = src_entry(t.flat(mat, row, col), SRC_COMP0);
+            (*src)[(base + plane_stride + e * 2) / 2] = src_entry(t.flat(mat, row, col), SRC_COMP1);
+        }
     };
     for (int u = 0; u < HU16; ++u)                      // alpha: entry g of [u][plane] = row 0, k = 8 g + e
         for (int g = 0; g < 4; ++g)
             for (int e = 0; e < 8; ++e)
-                put_small(T::OFF_SMALL + (size_t)(u * 2) * T::ALPHA_STRIDE + g * 16, T::ALPHA_STRIDE, e, t.w(MAT_ALPHA, 0, hseq16_channel(8 * u + e, g)));
+                put_small(T::OFF_SMALL + (size_t)(u * 2) * T::ALPHA_STRIDE + g * 16, T::ALPHA_STRIDE, e, MAT_ALPHA, 0, hseq16_channel(8 * u + e, g));
     for (int u = 0; u < VW / 32; ++u)                   // rgb: entry 3 g + row of [u][plane]
         for (int g = 0; g < 4; ++g)
             for (int row = 0; row < 3; ++row)
                 for (int e = 0; e < 8; ++e)
                     put_small(T::OFF_SMALL + T::SMALL_ALPHA + (size_t)(u * 2) * T::RGB_STRIDE + (3 * g + row) * 16, T::RGB_STRIDE, e,
-                              t.w(MAT_RGB, row, hseq16_channel(8 * u + e, g)));
+                              MAT_RGB, row, hseq16_channel(8 * u + e, g));
     return 0;
 }
 
-void pack_bias_s(const NetTensors& t, std::vector<float>& out) {
+void pack_bias_s(const NetTensors& t, std::vector<float>& out, std::vector<int32_t>* src) {
     out.assign(BIAS16_FLOATS, 0.f);
-    auto put = [&](int tile, const float* b, int n, int row0) {
+    if (src) src->assign(BIAS16_FLOATS, -1);
+    auto put = [&](int tile, const float* b, int tensor, int n, int row0) {
         for (int g = 0; g < G16; ++g)
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * g + r;
                 out[(size_t)tile * 16 + 4 * g + r] = (b && row < n) ? b[row] : 0.f;
+                if (src && b && row < n) (*src)[(size_t)tile * 16 + 4 * g + r] = src_entry(t.flat_bias(tensor, row), SRC_PLAIN);
             }
     };
     for (int l = 0; l < DEPTH; ++l)
-        for (int o = 0; o < NT16; ++o) put(BS_LAYER0 + l * NT16 + o, t.lb[l], W, 16 * o);
-    put(BS_ALPHA, t.alpha_b, 1, 0);
-    for (int o = 0; o < NTV16; ++o) put(BS_VIEWF + o, t.viewf_b.data(), VW, 16 * o);
-    put(BS_RGB, t.rgb_b, 3, 0);
+        for (int o = 0; o < NT16; ++o) put(BS_LAYER0 + l * NT16 + o, t.lb[l], 2 * l + 1, W, 16 * o);
+    put(BS_ALPHA, t.alpha_b, 17, 1, 0);
+    for (int o = 0; o < NTV16; ++o) put(BS_VIEWF + o, t.viewf_b.data(), NetTensors::SRC_VIEWF_B, VW, 16 * o);
+    put(BS_RGB, t.rgb_b, 23, 3, 0);
 }
 
 void pack_bias(const NetTensors& t, std::vector<float>& out) {

@@ -84,6 +84,7 @@ class HipRenderer:
         _ffi.check(self.lib, None, rc)
         self.handle = h
         self._state: Dict[str, dict] = {}
+        self._state_lazy: Dict[str, object] = {}      # state dicts to fetch from their owner on demand (load_network_device)
         self._chunk = cfg.chunk
 
     # -- lifetime ---------------------------------------------------------------------
@@ -119,6 +120,33 @@ class HipRenderer:
             self._check(self.lib.pg_set_framecodes(self.handle, which, codes.ctypes.data, codes.shape[0]))
         self._state["network_fn_state_dict" if which == 0 else "network_fine_state_dict"] = {
             k: torch.from_numpy(_np32(v).copy()) for k, v in sd.items()}
+
+    def load_network_device(self, which: int, tensors, codes=None, state_provider=None):
+        """New values of an already loaded net from DEVICE tensors (pg_load_weights_device): `tensors` = the 24 parameters in
+        NET_TENSOR_ORDER (contiguous fp32 on this device), `codes` the frame codes [n,16] when the config has them.  The packed
+        images of the fast paths are re-formed on the device; nothing is copied to the host.  `state_provider()` must return the
+        net's state dict (CPU tensors) when somebody asks this renderer for it (state_dict / parameters): until then the host
+        copy kept for checkpoints is stale."""
+        ts = [t.detach() for t in tensors]
+        for t in ts:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("load_network_device: contiguous float32 device tensors expected")
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        cptr, ncodes = None, 0
+        if self.cfg.framecode_ch > 0:
+            codes = codes.detach()
+            if not (codes.is_cuda and codes.dtype == torch.float32 and codes.is_contiguous()):
+                raise ValueError("load_network_device: contiguous float32 device frame codes expected")
+            cptr, ncodes = codes.data_ptr(), codes.shape[0]
+        self._check(self.lib.pg_load_weights_device(self.handle, self._stream(), which, ptrs, len(ts), cptr, ncodes))
+        self._state_lazy["network_fn_state_dict" if which == 0 else "network_fine_state_dict"] = state_provider
+
+    def _refresh_state(self):
+        """the host-side state dicts brought up to date after device-side weight loads"""
+        for key, provider in list(self._state_lazy.items()):
+            if provider is not None:
+                self._state[key] = {k: v.detach().cpu().clone() for k, v in provider().items()}
+            del self._state_lazy[key]
 
     def set_embedder(self, which: int, tau: float, cutoff_dist=None):
         """which 0 = embed_fn, 1 = embeddirs_fn (cutoff_embedder.py:89-94)."""
@@ -607,11 +635,13 @@ class HipRayCaster:
         return self
 
     def parameters(self):
+        self.renderer._refresh_state()
         for sd in self.renderer._state.values():
             for v in sd.values():
                 yield v
 
     def state_dict(self):
+        self.renderer._refresh_state()
         sd = {k: dict(v) for k, v in self.renderer._state.items()}
         sd.setdefault("embedbones_state_dict", {})
         return sd

@@ -243,11 +243,21 @@ class TrainableRayCaster(torch.nn.Module):
         net = self.network if which == 0 else self.network_fine
         return {k: v.detach().cpu() for k, v in net.state_dict().items()}
 
-    def sync_inference_weights(self):
-        """Re-pack the current parameter values for the fused inference kernels (after optimiser steps)."""
-        self.caster.renderer.load_network(0, self.net_state_dict(0))
-        if self.network_fine is not None:
-            self.caster.renderer.load_network(1, self.net_state_dict(1))
+    def sync_inference_weights(self, on_device: Optional[bool] = None):
+        """Hand the current parameter values to the fused inference kernels (after optimiser steps).  on_device (default:
+        whenever the renderer has one device): the packed weight images are re-formed on the GPU from the parameter tensors
+        themselves (pg_load_weights_device: no host copy, bitwise the host packing); False: through the host (pg_load_weights)."""
+        r = self.caster.renderer
+        if on_device is None:
+            on_device = len(getattr(r, "devices", [0])) <= 1
+        nets = [(0, self.network)] + ([(1, self.network_fine)] if self.network_fine is not None else [])
+        for which, net in nets:
+            if on_device:
+                p = dict(net.named_parameters())
+                codes = p["framecodes.codes.weight"] if self.cfg.framecode_ch > 0 else None
+                r.load_network_device(which, [p[k] for k in NET_TENSOR_ORDER], codes, state_provider=net.state_dict)
+            else:
+                r.load_network(which, self.net_state_dict(which))
         self._stale = False
 
     def _check_unused(self, unused):

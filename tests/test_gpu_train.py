@@ -378,3 +378,61 @@ def test_eval_render_after_a_step_uses_the_trained_weights_and_refuses_unknown_k
     for k in ("rgb_map", "acc_map"):
         assert float((ev[k] - tr[k].detach()).abs().max()) <= 1e-4, k
     m.renderer.close()
+
+
+@pytest.mark.parametrize("fc", [False, True])
+def test_device_side_weight_sync_equals_the_host_packing(fc):
+    """TrainableRayCaster.sync_inference_weights on the device (pg_load_weights_device: the packed images of the fast paths
+    re-formed by gather kernels from the parameter tensors, feature_linear folded into the view layer on the device) gives
+    BITWISE the renders of the host route (pg_load_weights) in every precision mode -- including the modes whose images are
+    re-packed from refreshed host copies (fp32, the direct kernels for short rays) -- after the parameters have moved; and
+    the state dict a checkpoint would take is the parameters'."""
+    import copy
+    from posegen_amd import h36m_config, surreal_config, synthetic as syn
+    from posegen_amd.raycaster import HipRayCaster
+    from posegen_amd.train import TrainableRayCaster
+    from bench import full_frame_rays
+    cfg = h36m_config(n_samples=64) if fc else surreal_config()
+    c = HipRayCaster.from_weights(cfg, *syn.make_model(cfg, 3), device=DEV, precision="bf16")
+    m = TrainableRayCaster(c)
+    rb, skts, cyl, *_ = full_frame_rays(96, 96, torch.device(DEV))
+    n = rb.shape[0]
+    cams = ((torch.arange(n, device=DEV) * 5) % cfg.n_framecodes).float() if fc else None
+    m.eval()
+    kw = dict(N_samples=64, skts=skts, cyls=cyl, cams=cams, N_importance=16)
+    with torch.no_grad():
+        m(rb, **kw)                                     # the default images exist
+        g = torch.Generator(device="cpu").manual_seed(11)
+        for p in m.parameters():                        # "optimiser steps"
+            if p.requires_grad:
+                p.add_(0.02 * torch.randn(p.shape, generator=g).to(p.device) * p.abs().mean())
+    outs = {}
+    for route in ("device", "host"):
+        m.sync_inference_weights(on_device=route == "device")
+        for prec, ns in (("bf16", 64), ("fp16", 64), ("fp16c", 64), ("fp32", 64), ("bf16", 40)):
+            c.renderer.set_precision(prec)
+            with torch.no_grad():
+                o = m(rb, **dict(kw, N_samples=ns))
+            outs[(route, prec, ns)] = {k: o[k].clone() for k in ("rgb_map", "acc_map", "disp_map")}
+        c.renderer.set_precision("bf16")
+    for (route, prec, ns), o in outs.items():
+        if route == "device":
+            for k, v in o.items():
+                assert torch.equal(v, outs[("host", prec, ns)][k]), (prec, ns, k)
+    # the parameters did move (the test would pass trivially otherwise), and a checkpoint taken from the inner caster follows them
+    sd = c.state_dict()["network_fn_state_dict"]
+    want = {k: v.detach().cpu() for k, v in m.network.state_dict().items()}
+    assert all(torch.equal(sd[k], want[k]) for k in want)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        m.sync_inference_weights(on_device=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        m.sync_inference_weights(on_device=False)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"sync_inference_weights: on the device {(t1 - t0) / 5 * 1e3:.2f} ms, through the host {(t2 - t1) / 5 * 1e3:.2f} ms")
+    c.renderer.close()

@@ -11,7 +11,7 @@ mkdir -p ../../build_ab
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ../../build_ab/${base}_$name.o
 objs=""
-for o in pg_api pg_eval16 pg_eval16r pg_rayrec pg_eval32 pg_evalc pg_evalc2 pg_kernels pg_train pg_pack; do
+for o in pg_api pg_repack pg_eval16 pg_eval16r pg_rayrec pg_eval32 pg_evalc pg_evalc2 pg_kernels pg_train pg_pack; do
   if [ "$o" = "$base" ]; then objs="$objs ../../build_ab/${base}_$name.o"; else objs="$objs ../_lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_ab/lib_$name.so $objs

@@ -15,8 +15,10 @@ m.eval()
 with torch.no_grad():
     m(rb, N_samples=64, skts=skts, cyls=cyl, N_importance=16)
 torch.cuda.synchronize()
-for rep in range(3):
-    t0 = time.perf_counter(); m.sync_inference_weights(); torch.cuda.synchronize(); t1 = time.perf_counter()
+for rep in range(6):
+    on_dev = rep >= 3
+    t0 = time.perf_counter(); m.sync_inference_weights(on_device=on_dev); th = time.perf_counter(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f"[{'device' if on_dev else 'host'} route] host time of the call {1e3 * (th - t0):.2f} ms;", end=" ")
     with torch.no_grad():
         m(rb, N_samples=64, skts=skts, cyls=cyl, N_importance=16)
     torch.cuda.synchronize(); t2 = time.perf_counter()
