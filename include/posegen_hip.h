@@ -434,6 +434,13 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
                   int64_t* stream_bytes, float* bias_out /* 82*32 floats or NULL */,
                   int32_t* chunk_bytes /* out: ring chunk size the library was built with */);
 
+/* Host-only: the source map of a packed image -- per 16-bit (form 0, 1) or fp32 (form 2) output element (flat source offset << 2)
+ * | kind (0 plain, 1 / 2 = plane 0 / 1 of the compensated pair), or -1 for a zero -- and the flat source vector it indexes (the
+ * 24 tensors in pg_load_weights order, then the folded view layer's weights and bias): what pg_load_weights_device gathers from.
+ * form 0: the on-chip stream of the 16x16x32 kernel, 1: pg_evalc2.hip's image, 2: the 16-row bias table. */
+int pg_debug_pack_map(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch, int form,
+                      int32_t* map_out, int64_t map_cap, int64_t* map_n, float* src_out, int64_t src_cap, int64_t* src_n);
+
 /* Host-only: the Y-stage weights of the factorised view layer (16-bit precisions), laid out
  * [wave 8][unit][64 lanes x 16 B] as the kernel reads them.  out may be NULL to query the size. */
 int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,

@@ -101,6 +101,8 @@ PROTOTYPES = {
     "pg_pose_kinematics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_double),
                                      C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_query_density": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pg_debug_pack_map": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "pg_debug_pack_vy": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_int64, C.POINTER(C.c_int64)]),
     "pg_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -986,6 +986,43 @@ int pg_debug_pack(const float* const* tensors, const int64_t* shapes, int n_tens
     return PG_OK;
 }
 
+// Host-only: the source map of a packed image (pg_load_weights_device re-forms the image from it by a gather) and the flat
+// source vector it indexes.  form 0: on-chip stream of the 16x16x32 kernel, 1: pg_evalc2.hip's image, 2: the 16-row bias table.
+int pg_debug_pack_map(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch, int form,
+                      int32_t* map_out, int64_t map_cap, int64_t* map_n, float* src_out, int64_t src_cap, int64_t* src_n) {
+    if (!tensors || !shapes || n_tensors != 24) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_map: need 24 tensors");
+    NetState ns;
+    ns.host.assign(24, {});
+    for (int i = 0; i < 24; ++i) ns.host[i].assign(tensors[i], tensors[i] + shapes[2 * i] * shapes[2 * i + 1]);
+    pg_config cfg{};
+    cfg.framecode_ch = framecode_ch;
+    pgpack::NetTensors t = tensors_of(ns, cfg);
+    t.layout(framecode_ch);
+    std::vector<int32_t> m;
+    std::vector<uint8_t> img;
+    std::vector<float> b;
+    int rc = 0;
+    if (form == 0) rc = pgpack::pack_stream_r(t, PG_PREC_BF16, img, true, &m);
+    else if (form == 1) rc = pgpack::pack_c2(t, framecode_ch > 0, img, &m);
+    else if (form == 2) pgpack::pack_bias_s(t, b, &m);
+    else return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_map: form 0, 1 or 2");
+    if (rc != 0) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_map: packing failed (%d)", rc);
+    const int64_t ns_ = t.off[pgpack::NetTensors::N_SRC];
+    if (map_n) *map_n = (int64_t)m.size();
+    if (src_n) *src_n = ns_;
+    if (map_out) {
+        if ((int64_t)m.size() > map_cap) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_map: map buffer too small");
+        std::memcpy(map_out, m.data(), m.size() * sizeof(int32_t));
+    }
+    if (src_out) {
+        if (ns_ > src_cap) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_map: source buffer too small");
+        for (int i = 0; i < 24; ++i) std::memcpy(src_out + t.off[i], ns.host[i].data(), ns.host[i].size() * sizeof(float));
+        std::memcpy(src_out + t.off[pgpack::NetTensors::SRC_VIEWF_W], t.viewf_w.data(), t.viewf_w.size() * sizeof(float));
+        std::memcpy(src_out + t.off[pgpack::NetTensors::SRC_VIEWF_B], t.viewf_b.data(), t.viewf_b.size() * sizeof(float));
+    }
+    return PG_OK;
+}
+
 int pg_debug_pack_vy(const float* const* tensors, const int64_t* shapes, int n_tensors, int framecode_ch,
                      int precision, uint8_t* out, int64_t cap, int64_t* out_bytes) {
     if (!tensors || !shapes || n_tensors != 24) return pg_fail(nullptr, PG_EINVAL, "pg_debug_pack_vy: need 24 tensors");

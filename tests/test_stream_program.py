@@ -727,3 +727,54 @@ def test_tile_split_weight_image_reproduces_mlp(fc):
     err = float(np.abs(raw - ref).max())
     print(f"pg_evalc2 weight image emulation vs fp32 oracle: {err:.2e} (|ref| max {np.abs(ref).max():.2f})")
     assert err <= 1e-4 * max(1.0, float(np.abs(ref).max()) / 10)
+
+
+# ---- source maps (pg_load_weights_device re-forms a packed image by a gather from the flat parameter vector) ----
+@pytest.mark.parametrize("fc", [False, True])
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_source_maps_reproduce_the_packed_images(form, fc):
+    """pg_debug_pack_map: gathering the flat source vector through the recorded map, with the conversion each entry names
+    (plain bf16 / fp16, plane 0 / 1 of the compensated pair, fp32 for the bias table), reproduces pg_debug_pack's image byte
+    for byte -- the host statement of what pg_repack.hip does on the device (the GPU test compares renders bitwise)."""
+    try:
+        lib = _ffi.load_library()
+    except _ffi.HipLibraryError as e:
+        pytest.skip(str(e))
+    cfg = h36m_config() if fc else surreal_config()
+    w = syn.make_weights(cfg, 5)
+    arrs = [np.ascontiguousarray(w[k], dtype=np.float32) for k in NET_TENSOR_ORDER]
+    ptrs = (C.c_void_p * 24)(*[a.ctypes.data for a in arrs])
+    shp = (C.c_int64 * 48)()
+    for i, a in enumerate(arrs):
+        shp[2 * i], shp[2 * i + 1] = a.shape[0], (a.shape[1] if a.ndim == 2 else 1)
+    nm, nsrc = C.c_int64(), C.c_int64()
+    assert lib.pg_debug_pack_map(ptrs, shp, 24, cfg.framecode_ch, form, None, 0, C.byref(nm), None, 0, C.byref(nsrc)) == 0, lib.pg_last_error(None)
+    mp, src = np.zeros(nm.value, dtype=np.int32), np.zeros(nsrc.value, dtype=np.float32)
+    assert lib.pg_debug_pack_map(ptrs, shp, 24, cfg.framecode_ch, form, mp.ctypes.data, nm.value, C.byref(nm), src.ctypes.data, nsrc.value, C.byref(nsrc)) == 0
+    valid = mp >= 0
+    vals = np.where(valid, src[np.where(valid, mp >> 2, 0)], 0.0).astype(np.float32)
+    kind = np.where(valid, mp & 3, 0)
+
+    def bf16_bits(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    if form == 2:
+        _, bias16, _, _ = pack(w, cfg, PREC_BF16, 3)
+        assert np.array_equal(vals.view(np.uint32), bias16[:vals.size].view(np.uint32))
+        assert int(valid.sum()) == 8 * 256 + 1 + 128 + 3
+        return
+    if form == 0:
+        for prec in (PREC_BF16, PREC_FP16):
+            img, _, _, _ = pack(w, cfg, prec, 3)
+            got = bf16_bits(vals) if prec == PREC_BF16 else vals.astype(np.float16).view(np.uint16)
+            assert (kind == 0).all() and np.array_equal(got, img.view(np.uint16)), prec
+        return
+    img, _, _, _ = pack(w, cfg, PREC_FP16C, 4)
+    wd = vals.astype(np.float64) / 129.0
+    w1 = wd.astype(np.float32).astype(np.float16).astype(np.float64)
+    p0 = (128.0 * w1).astype(np.float32).astype(np.float16).view(np.uint16)
+    p1 = (w1 + 129.0 * (wd - w1)).astype(np.float32).astype(np.float16).view(np.uint16)
+    got = np.where(kind == 1, p0, np.where(kind == 2, p1, 0)).astype(np.uint16)
+    got[~valid] = 0
+    assert set(np.unique(kind[valid])) == {1, 2} and np.array_equal(got, img.view(np.uint16))
