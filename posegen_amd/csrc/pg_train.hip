@@ -526,7 +526,17 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
 //     per lane straight from the registers: forward 82 - 108 us per layer, but dX -- whose mask loads then scatter too -- 140 - 160
 //     against bgemm128_kernel's 130).
 // Epilogue like bgemm128_kernel's: + cin (fp32, GEMM_ACC) + bias, ReLU, zero where the stored post-activation `mask` is <= 0.
-constexpr int LG_ROWS = 128, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = 2 * LG_BUF + 1024;
+// Tile geometry: ROWS rows per tile in NBUF buffers.  Measured (profiles/r5_train_lgemm_tiles.txt, 16-bit training step on one
+// box): 128 x 2 and 96 x 3 9.06 ms, 64 x 4 8.88 -- the same 128 KiB of LDS, three tiles of requests in flight instead of one.
+#ifndef PG_LG_ROWS
+#define PG_LG_ROWS 64
+#endif
+#ifndef PG_LG_NBUF
+#define PG_LG_NBUF 4
+#endif
+constexpr int LG_ROWS = PG_LG_ROWS, LG_NBUF = PG_LG_NBUF, LG_MT = LG_ROWS / 32, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = LG_NBUF * LG_BUF + 1024;
+constexpr int LG_PIECES = LG_MT * 16 / 8;            // LDS-DMA pieces per wave and tile
+static_assert(LG_ROWS % 32 == 0 && (LG_MT * 16) % 8 == 0 && LG_LDS <= 160 * 1024 && (LG_ROWS * 32) % 512 == 0, "tile geometry");
 __device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, unsigned lds_dst) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
 }
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
                                                        bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
                                                        const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lg_smem[];
-    float* bias_l = reinterpret_cast<float*>(lg_smem + 2 * LG_BUF);
+    float* bias_l = reinterpret_cast<float*>(lg_smem + LG_NBUF * LG_BUF);
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lg_smem;
@@ -543,36 +553,36 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8t*>(B + (long long)(32 * wv + li) * ldb + 16 * ks + 8 * kh);
     const int n_tiles = (M + LG_ROWS - 1) / LG_ROWS;
-    // this wave's 8 of a tile's 64 fragments: f = 8 wv + j = (row tile f >> 4, k-step f & 15)
+    // this wave's LG_PIECES of a tile's 16 LG_MT fragments: f = LG_PIECES wv + j = (row tile f >> 4, k-step f & 15)
     auto request = [&](int tile, int buf) {
         tile = min(tile, n_tiles - 1);
         const bf16_t* base = A + (long long)tile * LG_ROWS * lda;         // wave-uniform
         const int rows_left = M - tile * LG_ROWS;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = 8 * wv + j, mt = f >> 4, ks = f & 15;
+        for (int j = 0; j < LG_PIECES; ++j) {
+            const int f = LG_PIECES * wv + j, mt = f >> 4, ks = f & 15;
             const int row = min(32 * mt + li, rows_left - 1);            // rows past the end re-read the last one (never stored)
             lg_dma(base, (unsigned)((row * lda + 16 * ks + 8 * kh) * 2), lds0 + buf * LG_BUF + f * 1024);
         }
     };
-    int it = 0;
-    request(blockIdx.x, 0);
-    request(blockIdx.x + gridDim.x, 1);
-    asm volatile("" :: "v"(wf[0]), "v"(wf[15]) : "memory");       // (the weight loads are in front of the counted waits below)
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        f32x16 acc[4];
+    int buf = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int b = 0; b < LG_NBUF; ++b) request(blockIdx.x + b * (int)gridDim.x, b);
+    asm volatile("" :: "v"(wf[0]), "v"(wf[15]) : "memory");       // (the weight loads are in front of the counted waits below)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf = buf + 1 == LG_NBUF ? 0 : buf + 1) {
+        // everything but the pieces of the LG_NBUF - 1 tiles requested behind this one has arrived
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LG_NBUF - 1) * LG_PIECES) : "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x16 acc[LG_MT];
+#pragma unroll
+        for (int i = 0; i < LG_MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         const uint8_t* fb = lg_smem + buf * LG_BUF + lane * 16;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < LG_MT; ++mt)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8t*>(fb + (16 * mt + ks) * 1024), acc[mt], 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // every wave is done reading the buffer: it becomes the result tile's staging area
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
         // n: without the swizzle they would share a bank)
         uint8_t* stage = lg_smem + buf * LG_BUF;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < LG_MT; ++mt) {
             const int ml = 32 * mt + li;
             const long long m = (long long)tile * LG_ROWS + ml;
 #pragma unroll
@@ -614,19 +624,21 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
                 const unsigned h = ((k & 0x80000000u) == 0u && (k & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
                 return x & (l | h);
             };
+            constexpr int RPT = LG_ROWS / 16, GRP = RPT % 4 == 0 ? 4 : 3;      // rows per thread, in groups whose masks are in flight together
+            static_assert(RPT % GRP == 0, "rows per thread");
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {            // (two groups of four rows: the masks of a group are in flight together)
-                uint4 kk[4];
+            for (int jh = 0; jh < RPT / GRP; ++jh) {
+                uint4 kk[GRP];
                 if (mask) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const long long m = (long long)tile * LG_ROWS + r0 + 16 * (4 * jh + j);
+                    for (int j = 0; j < GRP; ++j) {
+                        const long long m = (long long)tile * LG_ROWS + r0 + 16 * (GRP * jh + j);
                         kk[j] = m < M ? *reinterpret_cast<const uint4*>(mask + m * ldm + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ml = r0 + 16 * (4 * jh + j);
+                for (int j = 0; j < GRP; ++j) {
+                    const int ml = r0 + 16 * (GRP * jh + j);
                     const long long m = (long long)tile * LG_ROWS + ml;
                     uint4 v = *reinterpret_cast<const uint4*>(stage + ml * 512 + ((ch ^ (ml & 31)) << 4));
                     if (mask) v = make_uint4(keep(v.x, kk[j].x), keep(v.y, kk[j].y), keep(v.z, kk[j].z), keep(v.w, kk[j].w));
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // the staging area has been read: the next request may overwrite it
         asm volatile("" ::: "memory");
-        request(tile + 2 * (int)gridDim.x, buf);
+        request(tile + LG_NBUF * (int)gridDim.x, buf);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA in flight when the wave exits
 }
