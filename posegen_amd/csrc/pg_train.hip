@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
 #ifndef PG_LG_NBUF
 #define PG_LG_NBUF 4
 #endif
-constexpr int LG_ROWS = PG_LG_ROWS, LG_NBUF = PG_LG_NBUF, LG_MT = LG_ROWS / 32, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = LG_NBUF * LG_BUF + 1024;
+constexpr int LG_ROWS = PG_LG_ROWS, LG_NBUF = PG_LG_NBUF, LG_MT = LG_ROWS / 32, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = LG_NBUF * LG_BUF + 2048;
 constexpr int LG_PIECES = LG_MT * 16 / 8;            // LDS-DMA pieces per wave and tile
 static_assert(LG_ROWS % 32 == 0 && (LG_MT * 16) % 8 == 0 && LG_LDS <= 160 * 1024 && (LG_ROWS * 32) % 512 == 0, "tile geometry");
 __device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, unsigned lds_dst) {
@@ -542,13 +542,17 @@ __device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, un
 }
 __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
                                                        bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
-                                                       const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin) {
+                                                       const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin,
+                                                       const float* __restrict__ r1_row, long long r1_ld, const float* __restrict__ r1_col) {
+    // r1_row / r1_col: + r1_row[m r1_ld] r1_col[n], a rank-1 term in fp32 (the alpha head's share of dH7 = d sigma (x) w_alpha: no
+    // [P, 256] fp32 array written by one kernel and read back by this one)
     extern __shared__ __attribute__((aligned(16))) uint8_t lg_smem[];
     float* bias_l = reinterpret_cast<float*>(lg_smem + LG_NBUF * LG_BUF);
+    float* col_l = bias_l + 256;
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, kh = lane >> 5;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lg_smem;
-    if (t < 256) bias_l[t] = bias ? bias[t] : 0.0f;
+    if (t < 256) { bias_l[t] = bias ? bias[t] : 0.0f; col_l[t] = r1_col ? r1_col[t] : 0.0f; }
     bf16x8t wf[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8t*>(B + (long long)(32 * wv + li) * ldb + 16 * ks + 8 * kh);
@@ -602,6 +606,11 @@ __global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __re
                 if ((flags & GEMM_ACC) && m < M) {
                     const float4 c4 = *reinterpret_cast<const float4*>(cin + m * ldcin + n0);
                     v[0] += c4.x; v[1] += c4.y; v[2] += c4.z; v[3] += c4.w;
+                }
+                if (r1_row) {
+                    const float gr = r1_row[min(m, (long long)M - 1) * r1_ld];
+                    const float4 c4 = *reinterpret_cast<const float4*>(col_l + n0);
+                    v[0] = fmaf(gr, c4.x, v[0]); v[1] = fmaf(gr, c4.y, v[1]); v[2] = fmaf(gr, c4.z, v[2]); v[3] = fmaf(gr, c4.w, v[3]);
                 }
                 const float4 b4 = *reinterpret_cast<const float4*>(bias_l + n0);
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -1013,10 +1022,16 @@ inline Tape* tape_of(pg_handle* h) {
 // C[M,N] = A B (+ bias, relu, accumulate); ksplit > 1: K in slices, summed into C in slice order (C is overwritten)
 // dt (DT_*): which of A, B, C and the mask are bf16 arrays (16-bit mode: the tape's activations); GEMM_ACC adds cin (fp32,
 // leading dimension ldcin; null: C itself, fp32)
+// C += row (x) col in fp32, row[m ld] a column of another array (gemm(): persistent layer kernel only)
+struct Rank1 { const float* row; long long ld; const float* col; };
+bool lgemm_enabled() {
+    static const bool on = [] { const char* e = std::getenv("POSEGEN_LGEMM"); return !(e && e[0] == '0'); }();
+    return on;
+}
 int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, int K, const void* A, long long sam, long long sak,
          const void* B, long long sbk, long long sbn, void* C, long long ldc, const float* bias, int flags, int ksplit = 1,
          const void* mask = nullptr, long long ldm = 0, float* rowsum = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0,
-         const KSeg2* seg2 = nullptr) {
+         const KSeg2* seg2 = nullptr, const Rank1* r1 = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
     Tape& t = *tape_of(h);
     if ((flags & GEMM_ACC) && !cin) {
@@ -1041,8 +1056,7 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
                (a_kcont ? K % qa == 0 : M % qa == 0) && (b_kcont ? K % qb == 0 : N % qb == 0);
     if ((abf || bbf) && !t.bf16) return pg_fail(h, PG_EINVAL, "bf16 GEMM operands outside the 16-bit mode");
     // a 256 x 256 layer of the 16-bit mode (forward / dX of the trunk's plain layers, feature_linear): the persistent kernel
-    static const bool lg_on = [] { const char* e = std::getenv("POSEGEN_LGEMM"); return !(e && e[0] == '0'); }();
-    if (lg_on && big && t.bf16 && abf && bbf && (dt & DT_C) && a_kcont && b_kcont && N == 256 && K == 256 && !seg2 && ksplit == 1 && !rowsum &&
+    if (lgemm_enabled() && big && t.bf16 && abf && bbf && (dt & DT_C) && a_kcont && b_kcont && N == 256 && K == 256 && !seg2 && ksplit == 1 && !rowsum &&
         sak == 1 && sbk == 1 && ldc % 8 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
         (!mask || ((dt & DT_M) && ldm % 8 == 0 && reinterpret_cast<uintptr_t>(mask) % 16 == 0)) &&
         (!(flags & GEMM_ACC) || (ldcin % 4 == 0 && reinterpret_cast<uintptr_t>(cin) % 16 == 0))) {
@@ -1053,10 +1067,12 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
         }
         const int tiles = (M + LG_ROWS - 1) / LG_ROWS;
         hipLaunchKernelGGL(lgemm256_kernel, dim3(std::min(tiles, h->n_cu)), dim3(512), LG_LDS, s, M, static_cast<const bf16_t*>(A), sam,
-                           static_cast<const bf16_t*>(B), sbn, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin);
+                           static_cast<const bf16_t*>(B), sbn, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin,
+                           r1 ? r1->row : nullptr, r1 ? r1->ld : 0, r1 ? r1->col : nullptr);
         PG_LAUNCH_CHECK(h, "lgemm256");
         return PG_OK;
     }
+    if (r1) return pg_fail(h, PG_EINVAL, "a rank-1 term outside the persistent layer kernel");
     if (big && !(a_kcont == false && b_kcont == true)) {
         const dim3 g((N + TB - 1) / TB, (M + TB - 1) / TB, ksplit);
         if (rowsum && (size_t)ksplit * g.x * M > RS_FLOATS) return pg_fail(h, PG_EINVAL, "row-sum scratch too small");
@@ -1155,7 +1171,7 @@ int linear_fwd2(pg_handle* h, hipStream_t s, long long P, int out, int in1, cons
 // dt: DT_A = dY, DT_C = dX, DT_M = relu_of are bf16
 int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, const void* dY, long long ldy, const void* W, long long ldw,
                  void* dX, long long ldx, int flags, const void* relu_of = nullptr, int dt = 0, const float* cin = nullptr, long long ldcin = 0,
-                 const bf16_t* WT = nullptr) {
+                 const bf16_t* WT = nullptr, const Rank1* r1 = nullptr) {
     // the heads (1 or 3 outputs, fp32 dY and weights): one pass that writes dX
     if ((out == 1 || out == 3) && !WT && flags == 0 && !(dt & (DT_A | DT_B)) && in % 8 == 0 && ldx % 8 == 0 && reinterpret_cast<uintptr_t>(dX) % 16 == 0 &&
         (!relu_of || reinterpret_cast<uintptr_t>(relu_of) % 16 == 0) &&
@@ -1171,7 +1187,8 @@ int linear_bwd_x(pg_handle* h, hipStream_t s, long long P, int out, int in, cons
         return PG_OK;
     }
     // WT: the step's transposed bf16 copy [in][out] of W's block -- both operands k-contiguous (16-byte tile stores, no transposing ones)
-    if (WT) return gemm(h, s, true, true, (int)P, in, out, dY, ldy, 1, WT, 1, out, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
+    if (WT) return gemm(h, s, true, true, (int)P, in, out, dY, ldy, 1, WT, 1, out, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin, nullptr, r1);
+    if (r1) return pg_fail(h, PG_EINVAL, "a rank-1 term needs the transposed weight copy");
     return gemm(h, s, true, false, (int)P, in, out, dY, ldy, 1, W, ldw, 1, dX, ldx, nullptr, flags, 1, relu_of, ldx, nullptr, dt, cin, ldcin);
 }
 // dW[out,in] = dY[P,out]^T X[P,in] (split-K over the points, slices summed in order); dt: DT_A = dY, DT_B = X are bf16
@@ -1297,9 +1314,14 @@ int mlp_backward(pg_handle* h, hipStream_t s, Tape& t, int net, const Pass& p, c
     const void* h7 = p.H[DEPTH - 1];
     PG_TRY(linear_bwd_w(h, s, P, W, W, dF, W, h7, W, g.w[18], W, g.w[19], AB));
     void* dH = t.tmpB;              // dH7 = (alpha's part + feature's part) * [H7 > 0]: the mask rides on the second GEMM
-    void* dpart = bf ? static_cast<void*>(t.tmpF) : dH;      // (16-bit mode: alpha's part in fp32, rounded once with the sum)
-    PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dpart, W, 0));
-    PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, GEMM_ACC, h7, ABCM, static_cast<const float*>(dpart), W, bf ? t.wbT[net][18] : nullptr));
+    if (bf && lgemm_enabled()) {    // 16-bit mode: alpha's part d sigma (x) w_alpha rides in the feature GEMM's epilogue as a rank-1 term (fp32)
+        const Rank1 r1{d_raw + 3, 4, w.w[16]};
+        PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, 0, h7, ABCM, nullptr, 0, t.wbT[net][18], &r1));
+    } else {
+        void* dpart = bf ? static_cast<void*>(t.tmpF) : dH;      // (16-bit mode: alpha's part in fp32, rounded once with the sum)
+        PG_TRY(linear_bwd_x(h, s, P, 1, W, d_raw + 3, 4, w.w[16], W, dpart, W, 0));
+        PG_TRY(linear_bwd_x(h, s, P, W, W, dF, W, WT(18, 0), W, dH, W, GEMM_ACC, h7, ABCM, static_cast<const float*>(dpart), W, bf ? t.wbT[net][18] : nullptr));
+    }
     PG_TRY(linear_bwd_w(h, s, P, 1, W, d_raw + 3, 4, h7, W, g.w[16], W, nullptr, B_));
     PG_TRY(colsum(h, s, d_raw + 3, P, 1, 4, g.w[17]));
     // the trunk, back to front: dZ_l = dH_l * [H_l > 0]
