@@ -835,19 +835,28 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(void* __restrict__ d, co
         if (!(ld_el(h, i, bf) > 0.0f)) st_el(d, i, 0.0f, bf);
 }
 
-// the 16-bit mode's copy of a weight matrix (rounded once per step, read by every tile of the step's GEMMs)
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long count) {
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (long long)gridDim.x * 256) dst[i] = f2bf(src[i]);
-}
-
-// ... and the transposed bf16 copy of the rows x cols block of a weight matrix (leading dimension ld) the dX GEMMs read: dst[c][r]
-__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, long long ld, int rows, int cols, bf16_t* __restrict__ dst) {
+// this step's bf16 copies of all weight matrices in ONE launch (38 launches of 3 us each were 0.2 ms of the step's timeline):
+// job = a plain copy [rows x cols, contiguous] or a transposed copy of a column block (source leading dimension ld)
+struct WJob { const float* src; bf16_t* dst; long long ld; int rows, cols, transpose; };
+constexpr int WJOBS_MAX = 64;
+struct WJobs { WJob j[WJOBS_MAX]; };
+__global__ __launch_bounds__(256) void cvt_weights_kernel(WJobs js) {
+    const WJob& j = js.j[blockIdx.y];
+    if (!j.transpose) {
+        const long long n = (long long)j.rows * j.cols;
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) j.dst[i] = f2bf(j.src[i]);
+        return;
+    }
     __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < rows && c0 + tx < cols) ? src[(long long)(r0 + i) * ld + c0 + tx] : 0.0f;
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < cols && r0 + tx < rows) dst[(long long)(c0 + i) * rows + r0 + tx] = f2bf(tile[tx][i]);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, tcols = (j.cols + 31) / 32, tiles = ((j.rows + 31) / 32) * tcols;
+    for (int tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
+        const int r0 = (tl / tcols) * 32, c0 = (tl % tcols) * 32;
+        for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < j.rows && c0 + tx < j.cols) ? j.src[(long long)(r0 + i) * j.ld + c0 + tx] : 0.0f;
+        __syncthreads();
+        for (int i = ty; i < 32; i += 8)
+            if (c0 + i < j.cols && r0 + tx < j.rows) j.dst[(long long)(c0 + i) * j.rows + r0 + tx] = f2bf(tile[tx][i]);
+        __syncthreads();
+    }
 }
 
 // part[block][n] = sum over the block's CS_ROWS rows of d[row * ld + n], N <= 4 (the heads' bias gradients: columns of d_raw;
@@ -1438,17 +1447,21 @@ int pg_train_forward(pg_handle* h, void* stream, int64_t n, const float* ray_bat
             t.wb[k][i] = (bf && wsize[i]) ? reinterpret_cast<bf16_t*>(take(wsize[i] * 2)) : nullptr;
             t.wbT[k][i] = (bf && tblock[i].rows) ? reinterpret_cast<bf16_t*>(take((size_t)tblock[i].rows * tblock[i].cols * 2)) : nullptr;
         }
-    if (bf) {       // this step's bf16 copies of the weight matrices (the parameters do not change between forward and backward)
+    if (bf) {       // this step's bf16 copies of the weight matrices (the parameters do not change between forward and backward): one launch
+        WJobs js{};
+        int nj = 0;
         for (int k = 0; k < (N > 0 ? 2 : 1); ++k)
             for (int i = 0; i < 24; ++i) {
                 if (!wsize[i]) continue;
-                hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)((wsize[i] + 1023) / 1024)), dim3(256), 0, s, (k ? fine : coarse)->w[i], t.wb[k][i], (long long)wsize[i]);
+                const float* src = (k ? fine : coarse)->w[i];
+                js.j[nj++] = WJob{src, t.wb[k][i], 0, 1, (int)wsize[i], 0};
                 if (tblock[i].rows) {
                     const long long ldw = (long long)(wsize[i] / tblock[i].rows);       // (= the matrix's column count)
-                    hipLaunchKernelGGL(cvt_bf16_t_kernel, dim3((tblock[i].cols + 31) / 32, (tblock[i].rows + 31) / 32), dim3(256), 0, s,
-                                       (k ? fine : coarse)->w[i] + tblock[i].col0, ldw, tblock[i].rows, tblock[i].cols, t.wbT[k][i]);
+                    js.j[nj++] = WJob{src + tblock[i].col0, t.wbT[k][i], ldw, tblock[i].rows, tblock[i].cols, 1};
                 }
             }
+        if (nj > WJOBS_MAX) return pg_fail(h, PG_EINVAL, "weight conversion: %d jobs", nj);
+        hipLaunchKernelGGL(cvt_weights_kernel, dim3(64, nj), dim3(256), 0, s, js);
         PG_LAUNCH_CHECK(h, "weight conversion");
     }
     t.part = take(PART_FLOATS * 4); t.rs_part = take(RS_FLOATS * 4); t.ray_g = take((size_t)n * FC_CH * 4);
