@@ -534,13 +534,16 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
 #ifndef PG_LG_NBUF
 #define PG_LG_NBUF 4
 #endif
+#ifndef PG_LG_WGS
+#define PG_LG_WGS 1         // workgroups per CU (2: half the LDS and 128 registers each -- measured slower, the kernel spills)
+#endif
 constexpr int LG_ROWS = PG_LG_ROWS, LG_NBUF = PG_LG_NBUF, LG_MT = LG_ROWS / 32, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = LG_NBUF * LG_BUF + 2048;
 constexpr int LG_PIECES = LG_MT * 16 / 8;            // LDS-DMA pieces per wave and tile
-static_assert(LG_ROWS % 32 == 0 && (LG_MT * 16) % 8 == 0 && LG_LDS <= 160 * 1024 && (LG_ROWS * 32) % 512 == 0, "tile geometry");
+static_assert(LG_ROWS % 32 == 0 && (LG_MT * 16) % 8 == 0 && LG_LDS * PG_LG_WGS <= 160 * 1024 && (LG_ROWS * 32) % 512 == 0, "tile geometry");
 __device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, unsigned lds_dst) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
 }
-__global__ __launch_bounds__(512) void lgemm256_kernel(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_WGS, 2 * PG_LG_WGS))) void lgemm256_kernel(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
                                                        bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
                                                        const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin,
                                                        const float* __restrict__ r1_row, long long r1_ld, const float* __restrict__ r1_col) {
@@ -1075,7 +1078,7 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
             attr_done.fetch_or(1ull << (h->device & 63), std::memory_order_release);
         }
         const int tiles = (M + LG_ROWS - 1) / LG_ROWS;
-        hipLaunchKernelGGL(lgemm256_kernel, dim3(std::min(tiles, h->n_cu)), dim3(512), LG_LDS, s, M, static_cast<const bf16_t*>(A), sam,
+        hipLaunchKernelGGL(lgemm256_kernel, dim3(std::min(tiles, PG_LG_WGS * h->n_cu)), dim3(512), LG_LDS, s, M, static_cast<const bf16_t*>(A), sam,
                            static_cast<const bf16_t*>(B), sbn, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin,
                            r1 ? r1->row : nullptr, r1 ? r1->ld : 0, r1 ? r1->col : nullptr);
         PG_LAUNCH_CHECK(h, "lgemm256");
