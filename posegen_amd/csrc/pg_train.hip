@@ -537,18 +537,34 @@ __global__ __launch_bounds__(256, PG_BGEMM_WGS) void bgemm128_kernel(int M, int 
 #ifndef PG_LG_WGS
 #define PG_LG_WGS 1         // workgroups per CU (2: half the LDS and 128 registers each -- measured slower, the kernel spills)
 #endif
-constexpr int LG_ROWS = PG_LG_ROWS, LG_NBUF = PG_LG_NBUF, LG_MT = LG_ROWS / 32, LG_BUF = LG_ROWS * 256 * 2, LG_LDS = LG_NBUF * LG_BUF + 2048;
-constexpr int LG_PIECES = LG_MT * 16 / 8;            // LDS-DMA pieces per wave and tile
-static_assert(LG_ROWS % 32 == 0 && (LG_MT * 16) % 8 == 0 && LG_LDS * PG_LG_WGS <= 160 * 1024 && (LG_ROWS * 32) % 512 == 0, "tile geometry");
+// Geometry of an instantiation: KS1 + KS2 k-steps of 16 (two input segments: [h | x] of the skip layer; KS2 = 0: one), ROWS rows per
+// tile, NBUF buffers.  The weights of both segments stay in registers (4 (KS1 + KS2) of them: 64 for a 256-wide layer, 108 for
+// layer 0's K = 432, 172 for the skip layer's 256 + 432).
+template <int KS1, int KS2, int ROWS, int NBUF>
+struct LG {
+    static constexpr int F = KS1 + KS2, MT = ROWS / 32, NFRAG = MT * F, BUF = NFRAG * 1024, LDS = NBUF * BUF + 2048;
+    static constexpr int JMAX = (NFRAG + 7) / 8;             // LDS-DMA pieces per wave and tile: JMAX, or JMAX - 1 for the waves past NFRAG % 8
+    static_assert(ROWS % 32 == 0 && LDS * PG_LG_WGS <= 160 * 1024 && (ROWS * 32) % 512 == 0 && BUF >= ROWS * 512 && KS1 > 0, "tile geometry");
+};
+using LG256 = LG<16, 0, PG_LG_ROWS, PG_LG_NBUF>;             // a 256 x 256 layer
+using LG432 = LG<27, 0, 32, 4>;                              // layer 0: K = 432
+using LGSKIP = LG<16, 27, 32, 3>;                            // the skip layer: [h (256) | x (432)]
 __device__ __forceinline__ void lg_dma(const bf16_t* base, unsigned lane_off, unsigned lds_dst) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(lane_off), "s"(base) : "memory");
 }
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_WGS, 2 * PG_LG_WGS))) void lgemm256_kernel(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
-                                                       bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
-                                                       const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin,
-                                                       const float* __restrict__ r1_row, long long r1_ld, const float* __restrict__ r1_col) {
+template <typename G>
+struct LGK;
+template <int KS1, int KS2, int ROWS, int NBUF>
+struct LGK<LG<KS1, KS2, ROWS, NBUF>> {
+    using G = LG<KS1, KS2, ROWS, NBUF>;
+    static __device__ __forceinline__ void run(int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb,
+                                               const bf16_t* __restrict__ A2, long long lda2, const bf16_t* __restrict__ B2, long long ldb2,
+                                               bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags,
+                                               const bf16_t* __restrict__ mask, long long ldm, const float* __restrict__ cin, long long ldcin,
+                                               const float* __restrict__ r1_row, long long r1_ld, const float* __restrict__ r1_col) {
     // r1_row / r1_col: + r1_row[m r1_ld] r1_col[n], a rank-1 term in fp32 (the alpha head's share of dH7 = d sigma (x) w_alpha: no
     // [P, 256] fp32 array written by one kernel and read back by this one)
+    constexpr int LG_ROWS = ROWS, LG_NBUF = NBUF, LG_MT = G::MT, LG_BUF = G::BUF;
     extern __shared__ __attribute__((aligned(16))) uint8_t lg_smem[];
     float* bias_l = reinterpret_cast<float*>(lg_smem + LG_NBUF * LG_BUF);
     float* col_l = bias_l + 256;
@@ -556,29 +572,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_W
     const int li = lane & 31, kh = lane >> 5;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lg_smem;
     if (t < 256) { bias_l[t] = bias ? bias[t] : 0.0f; col_l[t] = r1_col ? r1_col[t] : 0.0f; }
-    bf16x8t wf[16];
+    bf16x8t wf[G::F];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) wf[ks] = *reinterpret_cast<const bf16x8t*>(B + (long long)(32 * wv + li) * ldb + 16 * ks + 8 * kh);
+    for (int ks = 0; ks < KS1; ++ks) wf[ks] = *reinterpret_cast<const bf16x8t*>(B + (long long)(32 * wv + li) * ldb + 16 * ks + 8 * kh);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) wf[KS1 + ks] = *reinterpret_cast<const bf16x8t*>(B2 + (long long)(32 * wv + li) * ldb2 + 16 * ks + 8 * kh);
     const int n_tiles = (M + LG_ROWS - 1) / LG_ROWS;
-    // this wave's LG_PIECES of a tile's 16 LG_MT fragments: f = LG_PIECES wv + j = (row tile f >> 4, k-step f & 15)
+    // fragment f = (row tile f / F, k-step f % F of the concatenated input) of a tile; wave wv requests f = wv, wv + 8, ..
+    const bool full = wv < (G::NFRAG % 8 == 0 ? 8 : G::NFRAG % 8);         // this wave has JMAX pieces per tile (else JMAX - 1)
     auto request = [&](int tile, int buf) {
         tile = min(tile, n_tiles - 1);
-        const bf16_t* base = A + (long long)tile * LG_ROWS * lda;         // wave-uniform
+        const bf16_t* base1 = A + (long long)tile * LG_ROWS * lda;         // wave-uniform
+        const bf16_t* base2 = KS2 ? A2 + (long long)tile * LG_ROWS * lda2 : nullptr;
         const int rows_left = M - tile * LG_ROWS;
 #pragma unroll
-        for (int j = 0; j < LG_PIECES; ++j) {
-            const int f = LG_PIECES * wv + j, mt = f >> 4, ks = f & 15;
+        for (int j = 0; j < G::JMAX; ++j) {
+            const int f = wv + 8 * j;
+            if (j + 1 == G::JMAX && !full) break;
+            const int mt = f / G::F, fk = f - mt * G::F;
             const int row = min(32 * mt + li, rows_left - 1);            // rows past the end re-read the last one (never stored)
-            lg_dma(base, (unsigned)((row * lda + 16 * ks + 8 * kh) * 2), lds0 + buf * LG_BUF + f * 1024);
+            if (KS2 == 0 || fk < KS1) lg_dma(base1, (unsigned)((row * lda + 16 * fk + 8 * kh) * 2), lds0 + buf * LG_BUF + f * 1024);
+            else lg_dma(base2, (unsigned)((row * lda2 + 16 * (fk - KS1) + 8 * kh) * 2), lds0 + buf * LG_BUF + f * 1024);
         }
     };
     int buf = 0;
 #pragma unroll
     for (int b = 0; b < LG_NBUF; ++b) request(blockIdx.x + b * (int)gridDim.x, b);
-    asm volatile("" :: "v"(wf[0]), "v"(wf[15]) : "memory");       // (the weight loads are in front of the counted waits below)
+    asm volatile("" :: "v"(wf[0]), "v"(wf[G::F - 1]) : "memory");       // (the weight loads are in front of the counted waits below)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf = buf + 1 == LG_NBUF ? 0 : buf + 1) {
         // everything but the pieces of the LG_NBUF - 1 tiles requested behind this one has arrived
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LG_NBUF - 1) * LG_PIECES) : "memory");
+        if (full) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LG_NBUF - 1) * G::JMAX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LG_NBUF - 1) * (G::JMAX - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
         f32x16 acc[LG_MT];
 #pragma unroll
@@ -587,10 +611,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_W
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         const uint8_t* fb = lg_smem + buf * LG_BUF + lane * 16;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
+        for (int ks = 0; ks < G::F; ++ks)
 #pragma unroll
             for (int mt = 0; mt < LG_MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8t*>(fb + (16 * mt + ks) * 1024), acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], *reinterpret_cast<const bf16x8t*>(fb + (G::F * mt + ks) * 1024), acc[mt], 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // every wave is done reading the buffer: it becomes the result tile's staging area
         // registers -> LDS: row m of the tile at m * 512 B, its 16-byte chunk c at slot c ^ (m & 31) (a lane column is 32 rows at one
@@ -636,7 +660,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_W
                 const unsigned h = ((k & 0x80000000u) == 0u && (k & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
                 return x & (l | h);
             };
-            constexpr int RPT = LG_ROWS / 16, GRP = RPT % 4 == 0 ? 4 : 3;      // rows per thread, in groups whose masks are in flight together
+            constexpr int RPT = LG_ROWS / 16, GRP = RPT % 4 == 0 ? 4 : RPT % 3 == 0 ? 3 : RPT % 2 == 0 ? 2 : 1;      // rows per thread, in groups whose masks are in flight together
             static_assert(RPT % GRP == 0, "rows per thread");
 #pragma unroll
             for (int jh = 0; jh < RPT / GRP; ++jh) {
@@ -664,7 +688,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_W
         request(tile + LG_NBUF * (int)gridDim.x, buf);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA in flight when the wave exits
-}
+    }
+};
+#define PG_LG_ARGS int M, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ B, long long ldb, const bf16_t* __restrict__ A2, long long lda2,      \
+    const bf16_t* __restrict__ B2, long long ldb2, bf16_t* __restrict__ C, long long ldc, const float* __restrict__ bias, int flags, const bf16_t* __restrict__ mask,   \
+    long long ldm, const float* __restrict__ cin, long long ldcin, const float* __restrict__ r1_row, long long r1_ld, const float* __restrict__ r1_col
+#define PG_LG_PASS M, A, lda, B, ldb, A2, lda2, B2, ldb2, C, ldc, bias, flags, mask, ldm, cin, ldcin, r1_row, r1_ld, r1_col
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2 * PG_LG_WGS, 2 * PG_LG_WGS))) void lgemm256_kernel(PG_LG_ARGS) { LGK<LG256>::run(PG_LG_PASS); }
+__global__ __launch_bounds__(512) void lgemm432_kernel(PG_LG_ARGS) { LGK<LG432>::run(PG_LG_PASS); }
+__global__ __launch_bounds__(512) void lgemm_skip_kernel(PG_LG_ARGS) { LGK<LGSKIP>::run(PG_LG_PASS); }
 
 // ---- the heads' skinny products (alpha: 1 output on 256 inputs, rgb: 3 on 128): one pass over the activations at memory
 // speed instead of a 64-wide GEMM tile with 1-3 useful columns.  XT = the activations' element type; a row of K elements is
@@ -1067,22 +1099,32 @@ int gemm(pg_handle* h, hipStream_t s, bool a_kcont, bool b_kcont, int M, int N, 
     bool big = M >= 64 && N >= 64 && aligned(A, a_kcont ? sam : sak, abf) && aligned(B, b_kcont ? sbn : sbk, bbf) &&
                (a_kcont ? K % qa == 0 : M % qa == 0) && (b_kcont ? K % qb == 0 : N % qb == 0);
     if ((abf || bbf) && !t.bf16) return pg_fail(h, PG_EINVAL, "bf16 GEMM operands outside the 16-bit mode");
-    // a 256 x 256 layer of the 16-bit mode (forward / dX of the trunk's plain layers, feature_linear): the persistent kernel
-    if (lgemm_enabled() && big && t.bf16 && abf && bbf && (dt & DT_C) && a_kcont && b_kcont && N == 256 && K == 256 && !seg2 && ksplit == 1 && !rowsum &&
+    // a 256-wide layer of the 16-bit mode on the persistent kernel: K = 256 (forward / dX of the trunk's plain layers, feature_linear),
+    // K = 432 (layer 0) or the skip layer's two segments [h (256) | x (432)]
+    const bool seg_skip = seg2 && K == 256 && seg2->K == 432 && seg2->sam % 8 == 0 && seg2->sbn % 8 == 0 &&
+                          reinterpret_cast<uintptr_t>(seg2->A) % 16 == 0 && reinterpret_cast<uintptr_t>(seg2->B) % 16 == 0;
+    if (lgemm_enabled() && big && t.bf16 && abf && bbf && (dt & DT_C) && a_kcont && b_kcont && N == 256 && ksplit == 1 && !rowsum &&
+        ((!seg2 && (K == 256 || K == 432)) || seg_skip) &&
         sak == 1 && sbk == 1 && ldc % 8 == 0 && reinterpret_cast<uintptr_t>(C) % 16 == 0 &&
         (!mask || ((dt & DT_M) && ldm % 8 == 0 && reinterpret_cast<uintptr_t>(mask) % 16 == 0)) &&
         (!(flags & GEMM_ACC) || (ldcin % 4 == 0 && reinterpret_cast<uintptr_t>(cin) % 16 == 0))) {
-        static std::atomic<unsigned long long> attr_done{0};       // the opt-in to > 64 KiB of dynamic LDS is per (kernel, device)
-        if (!(attr_done.load(std::memory_order_acquire) & (1ull << (h->device & 63)))) {
-            PG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(lgemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LG_LDS));
-            attr_done.fetch_or(1ull << (h->device & 63), std::memory_order_release);
-        }
-        const int tiles = (M + LG_ROWS - 1) / LG_ROWS;
-        hipLaunchKernelGGL(lgemm256_kernel, dim3(std::min(tiles, PG_LG_WGS * h->n_cu)), dim3(512), LG_LDS, s, M, static_cast<const bf16_t*>(A), sam,
-                           static_cast<const bf16_t*>(B), sbn, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin,
-                           r1 ? r1->row : nullptr, r1 ? r1->ld : 0, r1 ? r1->col : nullptr);
-        PG_LAUNCH_CHECK(h, "lgemm256");
-        return PG_OK;
+        auto launch = [&](auto kern, int lds, int rows, int wgs, std::atomic<unsigned long long>& attr_done) -> int {
+            if (!(attr_done.load(std::memory_order_acquire) & (1ull << (h->device & 63)))) {      // the opt-in to > 64 KiB of dynamic LDS is per (kernel, device)
+                PG_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                attr_done.fetch_or(1ull << (h->device & 63), std::memory_order_release);
+            }
+            const int tiles = (M + rows - 1) / rows;
+            hipLaunchKernelGGL(kern, dim3(std::min(tiles, wgs * h->n_cu)), dim3(512), lds, s, M, static_cast<const bf16_t*>(A), sam,
+                               static_cast<const bf16_t*>(B), sbn, seg2 ? seg2->A : nullptr, seg2 ? seg2->sam : 0, seg2 ? seg2->B : nullptr,
+                               seg2 ? seg2->sbn : 0, static_cast<bf16_t*>(C), ldc, bias, flags, static_cast<const bf16_t*>(mask), ldm, cin, ldcin,
+                               r1 ? r1->row : nullptr, r1 ? r1->ld : 0, r1 ? r1->col : nullptr);
+            PG_LAUNCH_CHECK(h, "persistent layer GEMM");
+            return PG_OK;
+        };
+        static std::atomic<unsigned long long> done256{0}, done432{0}, done_skip{0};
+        if (seg2) return launch(lgemm_skip_kernel, LGSKIP::LDS, 32, 1, done_skip);
+        if (K == 432) return launch(lgemm432_kernel, LG432::LDS, 32, 1, done432);
+        return launch(lgemm256_kernel, LG256::LDS, PG_LG_ROWS, PG_LG_WGS, done256);
     }
     if (r1) return pg_fail(h, PG_EINVAL, "a rank-1 term outside the persistent layer kernel");
     if (big && !(a_kcont == false && b_kcont == true)) {
