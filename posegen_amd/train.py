@@ -243,6 +243,15 @@ class TrainableRayCaster(torch.nn.Module):
         net = self.network if which == 0 else self.network_fine
         return {k: v.detach().cpu() for k, v in net.state_dict().items()}
 
+    def _state_provider(self, net):
+        """What the inner caster's state_dict() / parameters() fetch after a device-side sync: the net's tensors -- after another
+        sync if the parameters have moved since, so that the state handed out is the state the kernels render with."""
+        def provide():
+            if self._stale:
+                self.sync_inference_weights()
+            return net.state_dict()
+        return provide
+
     def sync_inference_weights(self, on_device: Optional[bool] = None):
         """Hand the current parameter values to the fused inference kernels (after optimiser steps).  on_device (default:
         whenever the renderer has one device): the packed weight images are re-formed on the GPU from the parameter tensors
@@ -255,7 +264,7 @@ class TrainableRayCaster(torch.nn.Module):
             if on_device:
                 p = dict(net.named_parameters())
                 codes = p["framecodes.codes.weight"] if self.cfg.framecode_ch > 0 else None
-                r.load_network_device(which, [p[k] for k in NET_TENSOR_ORDER], codes, state_provider=net.state_dict)
+                r.load_network_device(which, [p[k] for k in NET_TENSOR_ORDER], codes, state_provider=self._state_provider(net))
             else:
                 r.load_network(which, self.net_state_dict(which))
         self._stale = False
