@@ -181,6 +181,7 @@ class TrainableRayCaster(torch.nn.Module):
         self._stale = False                              # the inference kernels' packed weights lag the parameters
         self.cfg = caster.cfg
         dev = caster.renderer.device
+        caster.renderer._refresh_state()                 # (a device-side weight load leaves the host copies to be fetched on demand)
         st = caster.renderer._state
         fc = self.cfg.framecode_ch > 0
         self._names = list(NET_TENSOR_ORDER) + (["framecodes.codes.weight"] if fc else [])
