@@ -1,6 +1,8 @@
 """GPU tests of the training step: `TrainableRayCaster` -- forward in training mode with a
 tape, loss on the host side of the ABI, `loss.backward()` through pg_train_backward -- against the reference's own
 autograd (fixtures tests/golden/train_grads*.npz, produced by tools/gen_golden.py from the imported reference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -65,10 +67,14 @@ def test_training_step_gradients_match_the_reference_autograd(name):
     m.renderer.close()
 
 
-def test_training_gradients_of_an_odd_batch_match_the_oracle_autograd():
+@pytest.mark.parametrize("train_precision", ["fp32", "bf16"])
+def test_training_gradients_of_an_odd_batch_match_the_oracle_autograd(train_precision):
     """A batch whose point count is not a multiple of 4 (25 rays x 33 + 7 samples) takes the small-tile GEMM with the
     ReLU mask and the bias sums as kernels of their own instead of fused into the large-tile GEMM: same gradients,
-    checked against the oracle under torch autograd (itself pinned to the reference's gradients on the fixtures)."""
+    checked against the oracle under torch autograd (itself pinned to the reference's gradients on the fixtures).
+    bf16: the same batch in the 16-bit mode -- 825 and 1000 rows end inside a tile of every persistent layer kernel
+    (64-row tiles of the 256-wide layers, 32-row tiles of layer 0 and of the skip layer: clamped requests, rows past
+    the end never stored) -- within the mode's own bounds (norms 2e-2, entries 0.1 of the tensor's largest)."""
     from oracle import anerf_oracle as orc
     from posegen_amd import surreal_config
     from posegen_amd.raycaster import HipRayCaster, make_training_draws
@@ -86,16 +92,26 @@ def test_training_gradients_of_an_odd_batch_match_the_oracle_autograd():
     ref = orc.render_rays(rb, sk, cy, oracle_cfg(cfg, tv, td), twc, twf, 33, 7, draws=draws)
     _loss_of(ref, target).backward()
     c = HipRayCaster.from_weights(cfg, wc, wf, float(tv), float(td), device=DEV, precision="fp32")
-    m = TrainableRayCaster(c)
+    m = TrainableRayCaster(c, train_precision=train_precision)
     m.train()
     out = m(rb, N_samples=33, skts=sk, cyls=cy, N_importance=7, draws={k: v.to(DEV) for k, v in draws.items()})
     _loss_of(out, target.to(DEV)).backward()
+    worst = 0.0
     for tag, net, refw in (("coarse", m.network, twc), ("fine", m.network_fine, twf)):
         for k, p in net.named_parameters():
             r = refw[k].grad.numpy().reshape(-1)
             got = p.grad.detach().cpu().numpy().reshape(-1)
             scale = max(float(np.abs(r).max()), float(np.linalg.norm(r)) / np.sqrt(r.size), 1e-12)
-            assert float(np.abs(got - r).max()) <= 2e-4 * scale + 1e-9, (tag, k, float(np.abs(got - r).max()), scale)
+            if train_precision == "fp32":
+                assert float(np.abs(got - r).max()) <= 2e-4 * scale + 1e-9, (tag, k, float(np.abs(got - r).max()), scale)
+            else:
+                rn = float(np.linalg.norm(r.astype(np.float64)))
+                nerr = abs(float(np.linalg.norm(got.astype(np.float64))) - rn) / max(rn, 1e-12)
+                verr = float(np.abs(got - r).max()) / scale
+                worst = max(worst, nerr, verr)
+                assert np.isfinite(got).all() and nerr <= 2e-2 and verr <= 1e-1, (tag, k, nerr, verr)
+    if train_precision != "fp32":
+        print(f"odd batch, 16-bit mode: worst relative gradient deviation {worst:.2e}")
     m.renderer.close()
 
 
@@ -436,3 +452,31 @@ def test_device_side_weight_sync_equals_the_host_packing(fc):
     t2 = time.perf_counter()
     print(f"sync_inference_weights: on the device {(t1 - t0) / 5 * 1e3:.2f} ms, through the host {(t2 - t1) / 5 * 1e3:.2f} ms")
     c.renderer.close()
+
+
+def test_persistent_layer_kernel_is_bitwise_the_tile_kernel(tmp_path):
+    """The persistent layer GEMM (lgemm256 / lgemm432 / lgemm_skip: weights in registers, rows by LDS-DMA) against the tile GEMM
+    it replaces (POSEGEN_LGEMM=0), a child process each, on an odd batch (rows ending inside a tile of every variant): the same
+    products summed in the same k order by the same MFMA, so every parameter gradient is BITWISE the same -- except the
+    tensors behind dH7, where the alpha head's share now enters as a rank-1 term in the feature GEMM's epilogue (one fma
+    instead of a rounded product and an add): there within 1e-6 of the tensor's largest entry."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    grads = {}
+    for v in ("1", "0"):
+        out = str(tmp_path / f"g{v}.pt")
+        run = subprocess.run([sys.executable, os.path.join(repo, "tests", "diag", "odd_batch_grads.py"), out], capture_output=True, text=True,
+                             timeout=300, env=dict(os.environ, POSEGEN_LGEMM=v), cwd=repo)
+        assert run.returncode == 0, run.stderr[-2000:]
+        grads[v] = torch.load(out)
+    same = differ = 0
+    for k, a in grads["1"].items():
+        b = grads["0"][k]
+        if torch.equal(a, b):
+            same += 1
+        else:
+            differ += 1
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), k
+            assert k.split(".", 1)[1] in ("pts_linears.7.weight", "pts_linears.7.bias") or "pts_linears" in k, k
+    print(f"persistent vs tile GEMM: {same} gradient tensors bitwise equal, {differ} within 1e-6 (behind the rank-1 fusion)")
+    assert same >= 40
